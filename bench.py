@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused particle-filter update (predict by SimStep + observation
+weight + systematic resample) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one belief update of the whole particle population.  The population
+is 10^8 particles (the size BASELINE.json's metric is quoted at) for every N:
+sharded by index over the N ranks (strong scaling).  Inputs are synthetic and
+generated on the device before the timed region; the timed region holds K
+updates between barriers + device synchronisation, max over ranks.
+
+Rank 0 prints one JSON line with the whole-job particle-steps/s, the roofline
+of the dominant kernel (fused step kernel, HIP-event timed) and a CPU baseline
+(the oracle restatement timed on this host, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
+SEED = 0x5EED
+ACTION = 0.2
+
+
+def alg_bytes_per_particle_step(H: int, D: int) -> int:
+    """Compulsory traffic of one fused update with int32 struct-of-arrays state and
+    fp64 weights: read prior once + write posterior once + write weight + read weight."""
+    W = 2 + H + D * (H - 1)
+    return 2 * 4 * W + 16
+
+
+def observations(pomdp, count):
+    """Observation sequence from one true trajectory stepped through the library."""
+    import epidemicmodeling_amd as em
+    true = em.initialbelief(pomdp, 1, seed=SEED ^ 0xABCDEF)
+    obs = []
+    for t in range(count):
+        o, _, _ = em.step_batch(true, ACTION, seed=SEED ^ 0x7275E, step=t, want_r=False)
+        obs.append(int(o[0]))
+    true.close()
+    return obs
+
+
+def cpu_baseline(pomdp, seconds_target=12.0):
+    """The oracle's complete update (port of the reference algorithm, OpenMP) on a bounded sample."""
+    import numpy as np
+    from oracle import pyoracle
+    orc = pyoracle.Oracle(pomdp.to_c())
+    L = pyoracle.lib()
+    threads = L.orc_max_threads()
+    n = 500_000
+    st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
+    _, mu, _ = orc.log_weights(st, ACTION, 0)
+    o = int(np.median(mu))
+    t0 = time.perf_counter()
+    updates = 0
+    while True:
+        st, info = orc.pf_update(st, ACTION, o, SEED, updates)
+        updates += 1
+        if time.perf_counter() - t0 > seconds_target or updates >= 40:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n * updates / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{updates} complete updates of {n} particles (oracle/epi_oracle.c, OpenMP {threads} threads, "
+                      f"default parameters, a={ACTION})"}
+
+
+def run_single(args):
+    import torch
+    import epidemicmodeling_amd as em
+    from epidemicmodeling_amd._lib import check
+
+    pomdp = em.make_pomdp()
+    n = args.particles
+    obs = observations(pomdp, args.warmup + args.steps)
+    b = em.initialbelief(pomdp, n, seed=SEED)
+    ctx, lib = b.ctx, b.ctx.lib
+    for t in range(args.warmup):
+        check(lib.epi_pf_update_async(ctx.handle, b.handle, ACTION, obs[t], SEED, t))
+    ll, ess, fl = C.c_double(), C.c_double(), C.c_uint32()
+    check(lib.epi_pf_collect(ctx.handle, b.handle, C.byref(ll), C.byref(ess), C.byref(fl)))
+    check(lib.epi_ctx_timing(ctx.handle, 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        check(lib.epi_pf_update_async(ctx.handle, b.handle, ACTION, obs[t], SEED, t))
+    check(lib.epi_pf_collect(ctx.handle, b.handle, C.byref(ll), C.byref(ess), C.byref(fl)))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ksum, kcnt = C.c_double(), C.c_int64()
+    check(lib.epi_ctx_timing_read(ctx.handle, C.byref(ksum), C.byref(kcnt)))
+    check(lib.epi_ctx_timing(ctx.handle, 0))
+    return pomdp, n, dt, ksum.value / max(kcnt.value, 1), dict(loglik=ll.value, ess=ess.value, flags=fl.value)
+
+
+def run_sharded(args):
+    import torch
+    import torch.distributed as dist
+    import epidemicmodeling_amd as em
+    from epidemicmodeling_amd.distributed import ShardedFilter
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    pomdp = em.make_pomdp()
+    n = args.particles
+    obs = observations(pomdp, args.warmup + args.steps) if rank == 0 else None
+    box = [obs]
+    dist.broadcast_object_list(box, src=0)
+    obs = box[0]
+    f = ShardedFilter(pomdp, n, seed=SEED, device=local)
+    f.init_normal(10_000.0, 5_000.0)
+    for t in range(args.warmup):
+        f.update(ACTION, obs[t])
+    f.timing(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        info = f.update(ACTION, obs[t])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ksum, kcnt = f.timing_read()
+    tt = torch.tensor([dt, ksum / max(kcnt, 1)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, kms = float(tt[0]), float(tt[1])
+    dist.destroy_process_group()
+    return pomdp, n, dt, kms, dict(loglik=info["loglik"], ess=info["ess"], flags=info["flags"]), rank
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = 0
+    if args.gpus > 1:
+        pomdp, n, dt, kms, diag, rank = run_sharded(args)
+    else:
+        pomdp, n, dt, kms, diag = run_single(args)
+    if rank != 0:
+        return
+    H, D = pomdp.horizon, pomdp.test_delay
+    balg = alg_bytes_per_particle_step(H, D)
+    value = n * args.steps / dt
+    n_launch = n // args.gpus                       # particles one launch of the fused kernel processes
+    achieved = balg * n_launch / (kms * 1e-3) / 1e9 if kms > 0 else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["k_step_hbm_bytes_per_particle"] * n_launch
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "particle-steps/sec (whole node) at 10^8 particles; % of HBM roofline",
+        "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "int32 counts / f64 sampler arithmetic", "data": "synthetic",
+        "config": {"workload": "bootstrap particle-filter update (predict+weight+systematic resample)",
+                   "particles": n, "H": H, "test_delay": D, "N": pomdp.N, "action": ACTION, "seed": SEED,
+                   "sharding": f"by index over {args.gpus} rank(s)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                     "kernel": "k_step<weigh>", "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
+        "diagnostics": diag,
+    }
+    if args.gpus == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(pomdp)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

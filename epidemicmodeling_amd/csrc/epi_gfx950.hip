@@ -1,0 +1,1414 @@
+// libepi_gfx950: HIP kernels for the InfectionSim particle step and the
+// bootstrap particle-filter update on gfx950 (MI355X), and the C ABI of
+// include/epi.h on top of them.
+//
+// Kernels (all one thread per particle or per output slot, 256-thread
+// workgroups = 4 wave64, coalesced struct-of-arrays rows):
+//   k_step        fused [gather by ancestor] + observation weight + SimStep
+//   k_wsum        fixed-point weights: per-workgroup totals
+//   k_wscan       single-workgroup exclusive scan of those totals
+//   k_wcum        fixed-point weights again + workgroup prefix scan -> C[i]
+//   k_select      systematic resampling: ancestor of every output slot by
+//                 binary search in C
+//   k_export / k_import / k_gather   move resampled particles
+//   k_sums        integer column sums (belief mean)
+//   k_init_*      initial particles
+//
+// The filter keeps the posterior as (propagated particles, ancestor index):
+// the gather of resampled particles is folded into the next k_step, so one
+// update reads each prior particle once and writes each posterior particle
+// once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include "epi_step.hpp"
+
+using namespace epi;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHECK(expr)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(EPI_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char* epi_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+struct DevScalars {
+    unsigned long long lwmax_bits;  // order-preserving code of the local max log weight
+    double lwmax;                   // max log weight the fixed-point weights are relative to
+    unsigned long long w_local;     // local total of fixed-point weights
+    unsigned long long w_off;       // cumulative weight of the shards before this one
+    unsigned long long w_total;     // total over all shards
+    double sumsq;                   // local sum of squared fixed-point weights
+    unsigned int flags;
+    unsigned int pad;
+};
+
+struct epi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    epi_params P;
+    bool have_params = false;
+    DevScalars* d_scal = nullptr;
+    long long* d_sums = nullptr;        // 2 + H + (D+1) H column sums
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    bool timing = false;                // record an event pair around every fused step kernel of an update
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
+};
+
+enum Phase { PH_IDLE = 0, PH_PREDICTED = 1, PH_WEIGHED = 2 };
+
+struct epi_belief {
+    epi_ctx* ctx = nullptr;
+    int64_t n = 0, halo_cap = 0, stride = 0;
+    int64_t n_total = 0, slot0 = 0;
+    int rows = 0;
+    int32_t* buf[2] = {nullptr, nullptr};
+    int cur = 0;
+    int32_t* anc = nullptr;
+    bool has_anc = false;
+    double* lw = nullptr;               // log weights, then (same memory) uint64 cumulative weights
+    unsigned long long* blocksum = nullptr;
+    double* blocksq = nullptr;
+    int64_t nblocks = 0;
+    int phase = PH_IDLE;
+    int64_t halo_used = 0;
+    int frac_bits = 0;
+    uint64_t seed = 0; uint32_t step = 0;
+};
+
+static const int TPB = 256;            // threads per workgroup
+static const int SCAN_ITEMS = 8;       // fixed-point weights per thread in the scan kernels
+static const int SCAN_TILE = TPB * SCAN_ITEMS;
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long order_code(double x)
+{
+    unsigned long long b = d2u(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ __forceinline__ double order_decode(unsigned long long c)
+{
+    unsigned long long b = (c >> 63) ? (c & 0x7fffffffffffffffULL) : ~c;
+    return u2d(b);
+}
+
+__device__ __forceinline__ unsigned long long shfl_down_u64(unsigned long long v, int d)
+{
+    unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+    lo = __shfl_down(lo, d, 64); hi = __shfl_down(hi, d, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int d)
+{
+    unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+    lo = __shfl_up(lo, d, 64); hi = __shfl_up(hi, d, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_down_f64(double v, int d) { return u2d(shfl_down_u64(d2u(v), d)); }
+
+// ---------------------------------------------------------------------------
+// k_step: [gather] + [weight] + SimStep
+// ---------------------------------------------------------------------------
+struct StepArgs {
+    int64_t n;                  // particles handled by this launch
+    const int32_t* in; int64_t in_stride;
+    const int32_t* anc;         // source column of each particle in `in`, or null = identity
+    int32_t* out; int64_t out_stride;
+    double a; const double* a_dev; int64_t a_row_stride;   // action: scalar or a_dev[m * a_row_stride + a_col]
+    int64_t a_col;
+    double a_prev; const double* a_prev_dev; int64_t a_prev_col;   // previous action: scalar or a_prev_dev[m * a_row_stride + a_prev_col]
+    uint64_t seed; uint32_t step; uint64_t slot0;
+    // filter
+    double o; double* lw; DevScalars* scal;
+    // optional per-particle outputs
+    int32_t* o_out; double* r_out; int32_t* newinf_out;
+    // optional history row of a rollout: hist[c * n + m], c = 0..3
+    int32_t* hist;
+    // injected variates
+    const int32_t* inj_sympt; const int32_t* inj_pos; const double* inj_gam;
+    int32_t* pos_out;
+    // recorded variates (MODE_RECORD)
+    int32_t* rec_sympt; int32_t* rec_pos; double* rec_gam;
+};
+
+enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
+
+template <bool WEIGH, int MODE>
+__global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const epi_params P)
+{
+    __shared__ unsigned long long s_max[TPB / 64];
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    unsigned long long code = 0ULL;       // below every real code
+    unsigned int flags = 0;
+    if (m < A.n) {
+        const int64_t src = A.anc ? (int64_t)A.anc[m] : m;
+        const double a = A.a_dev ? A.a_dev[m * A.a_row_stride + A.a_col] : A.a;
+        StepResult res;
+        int32_t s_pre = 0, r_pre = 0, suminf_pre = 0;
+        if (A.hist) {
+            s_pre = A.in[src]; r_pre = A.in[A.in_stride + src];
+            for (int i = 0; i < P.H; i++) suminf_pre += A.in[(int64_t)(2 + i) * A.in_stride + src];
+        }
+        if constexpr (MODE == MODE_INJECT) {
+            InjectedDraws d{A.inj_sympt, A.inj_pos, A.inj_gam, A.n, m};
+            res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
+        } else if constexpr (MODE == MODE_RECORD) {
+            RecordingDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
+            res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
+        } else {
+            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step)};
+            res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
+        }
+        flags = res.flags;
+        if constexpr (WEIGH) {
+            double lw = log_weight(res.mu, res.var, A.o);
+            A.lw[m] = lw;
+            code = order_code(lw);
+        }
+        if (A.o_out) A.o_out[m] = res.o;
+        if (A.newinf_out) A.newinf_out[m] = res.new_inf;
+        if (A.r_out) {
+            double ap = A.a_prev_dev ? A.a_prev_dev[m * A.a_row_stride + A.a_prev_col] : A.a_prev;
+            A.r_out[m] = reward_of(P, res.sum_inf, a, ap);
+        }
+        if (A.hist) {
+            A.hist[m] = s_pre; A.hist[A.n + m] = suminf_pre; A.hist[2 * A.n + m] = r_pre; A.hist[3 * A.n + m] = res.o;
+        }
+    }
+    // flags: one atomic per wave that saw any
+    unsigned int wf = flags;
+    for (int d = 32; d >= 1; d >>= 1) wf |= __shfl_down(wf, d, 64);
+    if ((threadIdx.x & 63) == 0 && wf) atomicOr(&A.scal->flags, wf);
+    if constexpr (WEIGH) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            unsigned long long o = shfl_down_u64(code, d);
+            code = o > code ? o : code;
+        }
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = code;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long c = s_max[0];
+            for (int w = 1; w < TPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
+            atomicMax(&A.scal->lwmax_bits, c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fixed-point weights and their prefix sums
+//   wq_i = floor(exp(lw_i - lwmax) * 2^F)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long quantize(double lw, double lwmax, double scale)
+{
+    return (unsigned long long)__builtin_floor(s_exp(lw - lwmax) * scale);
+}
+
+__global__ void k_scal_reset(DevScalars* s)
+{
+    s->lwmax_bits = 0ULL; s->lwmax = 0.0; s->w_local = 0ULL; s->w_off = 0ULL; s->w_total = 0ULL; s->sumsq = 0.0;
+}
+// single-device update: the local maximum is the global one
+__global__ void k_scal_lwmax_local(DevScalars* s) { s->lwmax = s->lwmax_bits ? order_decode(s->lwmax_bits) : -__builtin_inf(); }
+__global__ void k_scal_total_local(DevScalars* s) { s->w_off = 0ULL; s->w_total = s->w_local; }
+
+__global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restrict__ lw, const DevScalars* __restrict__ scal, int F,
+                                               unsigned long long* __restrict__ blocksum, double* __restrict__ blocksq)
+{
+    __shared__ unsigned long long s_sum[TPB / 64];
+    __shared__ double s_sq[TPB / 64];
+    const double lwmax = scal->lwmax;
+    const double scale = u2d((uint64_t)(F + 1023) << 52);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long sum = 0ULL;
+    double sq = 0.0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        int64_t i = base + j;
+        if (i < n) {
+            unsigned long long w = quantize(lw[i], lwmax, scale);
+            sum += w;
+            double wd = (double)w;
+            sq += wd * wd;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { sum += shfl_down_u64(sum, d); sq += shfl_down_f64(sq, d); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_sq[threadIdx.x >> 6] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0ULL; double q = 0.0;
+        for (int w = 0; w < TPB / 64; w++) { t += s_sum[w]; q += s_sq[w]; }
+        blocksum[blockIdx.x] = t; blocksq[blockIdx.x] = q;
+    }
+}
+
+// one workgroup: exclusive scan of blocksum in place, totals to scal
+__global__ __launch_bounds__(1024) void k_wscan(int64_t nb, unsigned long long* __restrict__ blocksum, const double* __restrict__ blocksq,
+                                                DevScalars* __restrict__ scal)
+{
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_carry;
+    __shared__ double s_q[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_carry = 0ULL;
+    double sq = 0.0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        int64_t i = base + t;
+        unsigned long long v = i < nb ? blocksum[i] : 0ULL;
+        if (i < nb) sq += blocksq[i];
+        unsigned long long incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = shfl_up_u64(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        unsigned long long woff = 0ULL;
+        for (int w = 0; w < wv; w++) woff += s_w[w];
+        unsigned long long carry = s_carry;
+        if (i < nb) blocksum[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (t == 1023) s_carry = carry + woff + incl;
+        __syncthreads();
+    }
+    for (int d = 32; d >= 1; d >>= 1) sq += shfl_down_f64(sq, d);
+    if (lane == 0) s_q[wv] = sq;
+    __syncthreads();
+    if (t == 0) {
+        double q = 0.0;
+        for (int w = 0; w < 16; w++) q += s_q[w];
+        scal->w_local = s_carry;
+        scal->sumsq = q;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_wcum(int64_t n, double* __restrict__ lw_then_cum, const DevScalars* __restrict__ scal, int F,
+                                               const unsigned long long* __restrict__ blockoff)
+{
+    __shared__ unsigned long long s_w[TPB / 64];
+    const double lwmax = scal->lwmax;
+    const double scale = u2d((uint64_t)(F + 1023) << 52);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long v[SCAN_ITEMS];
+    unsigned long long run = 0ULL;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        int64_t i = base + j;
+        unsigned long long w = (i < n) ? quantize(lw_then_cum[i], lwmax, scale) : 0ULL;
+        run += w;
+        v[j] = run;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long incl = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = shfl_up_u64(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long off = blockoff[blockIdx.x] + (incl - run);
+    for (int w = 0; w < wv; w++) off += s_w[w];
+    unsigned long long* cum = reinterpret_cast<unsigned long long*>(lw_then_cum);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        int64_t i = base + j;
+        if (i < n) cum[i] = off + v[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// systematic resampling
+//   T_m = fl(fl(m + u) * fl(W / n_total)); ancestor = #{ i : C_i <= floor(T_m) }
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int64_t find_ancestor(const unsigned long long* __restrict__ cum, int64_t n_local,
+                                                 const DevScalars* __restrict__ scal, int64_t n_total, double u, int64_t m_global,
+                                                 int64_t slot0)
+{
+    const unsigned long long W = scal->w_total;
+    if (W == 0ULL) {                        // every weight zero: keep the particle in place
+        int64_t i = m_global - slot0;
+        return i < 0 ? 0 : (i >= n_local ? n_local - 1 : i);
+    }
+    const double stepw = (double)W / (double)n_total;
+    const double Tm = ((double)m_global + u) * stepw;
+    unsigned long long tq = (unsigned long long)__builtin_floor(Tm);
+    const unsigned long long off = scal->w_off;
+    tq = tq > off ? tq - off : 0ULL;
+    int64_t lo = 0, hi = n_local;           // first index with cum > tq
+    while (lo < hi) {
+        int64_t mid = lo + ((hi - lo) >> 1);
+        if (cum[mid] > tq) hi = mid; else lo = mid + 1;
+    }
+    return lo > n_local - 1 ? n_local - 1 : lo;
+}
+
+__global__ __launch_bounds__(TPB) void k_select(int64_t count, int64_t slot_begin, int64_t slot0, const unsigned long long* __restrict__ cum,
+                                                 int64_t n_local, const DevScalars* __restrict__ scal, int64_t n_total, double u,
+                                                 int32_t* __restrict__ anc)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= count) return;
+    const int64_t m = slot_begin + j;
+    anc[m - slot0] = (int32_t)find_ancestor(cum, n_local, scal, n_total, u, m, slot0);
+}
+
+// resampled particles of slots [slot_begin, slot_begin + count) packed as dst[row * count + j]
+__global__ __launch_bounds__(TPB) void k_export(int64_t count, int64_t slot_begin, int64_t slot0, const unsigned long long* __restrict__ cum,
+                                                 int64_t n_local, const DevScalars* __restrict__ scal, int64_t n_total, double u,
+                                                 const int32_t* __restrict__ src, int64_t stride, int rows, int32_t* __restrict__ dst)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= count) return;
+    const int64_t a = find_ancestor(cum, n_local, scal, n_total, u, slot_begin + j, slot0);
+    for (int r = 0; r < rows; r++) dst[(int64_t)r * count + j] = src[(int64_t)r * stride + a];
+}
+
+__global__ __launch_bounds__(TPB) void k_import(int64_t count, int64_t local_begin, int64_t halo_begin, const int32_t* __restrict__ src,
+                                                 int32_t* __restrict__ dst, int64_t stride, int rows, int32_t* __restrict__ anc)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= count) return;
+    for (int r = 0; r < rows; r++) dst[(int64_t)r * stride + halo_begin + j] = src[(int64_t)r * count + j];
+    anc[local_begin + j] = (int32_t)(halo_begin + j);
+}
+
+// dst column m = src column anc[m]
+__global__ __launch_bounds__(TPB) void k_gather(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
+                                                 int32_t* __restrict__ dst, int rows)
+{
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (m >= n) return;
+    const int64_t a = anc ? (int64_t)anc[m] : m;
+    for (int r = 0; r < rows; r++) dst[(int64_t)r * stride + m] = src[(int64_t)r * stride + a];
+}
+
+// sums[row] += sum over particles of state[row][anc[m]]; blockIdx.y = row
+__global__ __launch_bounds__(TPB) void k_sums(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
+                                               long long* __restrict__ sums)
+{
+    __shared__ long long s_p[TPB / 64];
+    const int row = blockIdx.y;
+    long long acc = 0;
+    for (int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x; m < n; m += (int64_t)gridDim.x * TPB) {
+        const int64_t a = anc ? (int64_t)anc[m] : m;
+        acc += (long long)src[(int64_t)row * stride + a];
+    }
+    unsigned long long v = (unsigned long long)acc;
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = (long long)v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < TPB / 64; w++) t += s_p[w];
+        atomicAdd(reinterpret_cast<unsigned long long*>(&sums[row]), (unsigned long long)t);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bare samplers (element j draws from the streams of slot j)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_sample_binomial(int64_t count, const int32_t* __restrict__ n, const double* __restrict__ p,
+                                                          uint64_t seed, uint32_t step, uint32_t bin, int which, int32_t* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= count) return;
+    Rng g = rng_make(seed, (uint64_t)j, step);
+    uint32_t w[4];
+    rng_block(g, K_BINOM0, bin, 0, w);
+    out[j] = which ? binomial_draw(n[j], p[j], w[2], w[3], g, K_POS, bin) : binomial_draw(n[j], p[j], w[0], w[1], g, K_SYMPT, bin);
+}
+
+__global__ __launch_bounds__(TPB) void k_sample_gamma(int64_t count, const double* __restrict__ shape, const double* __restrict__ scale,
+                                                       uint64_t seed, uint32_t step, uint32_t bin, double* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= count) return;
+    Rng g = rng_make(seed, (uint64_t)j, step);
+    out[j] = gamma_draw(shape[j], scale[j], g, bin);
+}
+
+// ---------------------------------------------------------------------------
+// initial particles
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t round_half_even(double x) { return (int32_t)__builtin_rint(x); }
+
+// State(Normal(mu, sigma), params): I_i = round(truncated-normal draw), S = N - sum I, R = 0
+__global__ __launch_bounds__(TPB) void k_init_normal(int64_t n, int32_t* __restrict__ out, int64_t stride, int H, int rows, long long N,
+                                                      double mu, double sigma, uint64_t seed, uint64_t slot0)
+{
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (m >= n) return;
+    Rng g = rng_make(seed, slot0 + (uint64_t)m, 0);
+    long long tot = 0;
+    for (int i = 0; i < H; i++) {
+        double x = 0.0;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t att = 0; att < 512u; att++) {
+            if ((att & 1u) == 0u) rng_block(g, K_INIT, (uint32_t)i, att >> 1, w);
+            float z0, z1;
+            if ((att & 1u) == 0u) box_muller(w[0], w[1], z0, z1); else box_muller(w[2], w[3], z0, z1);
+            double cand = mu + sigma * (double)z0;
+            if (cand >= 0.0) { x = cand; break; }
+        }
+        int32_t v = round_half_even(x);
+        out[(int64_t)(2 + i) * stride + m] = v;
+        tot += v;
+    }
+    out[m] = (int32_t)(N - tot);
+    out[stride + m] = 0;
+    for (int r = 2 + H; r < rows; r++) out[(int64_t)r * stride + m] = 0;
+}
+
+// State(params): Bayesian-bootstrap split of N into (S, inf, R) and of inf into I[1..H]
+__global__ __launch_bounds__(TPB) void k_init_simplex(int64_t n, int32_t* __restrict__ out, int64_t stride, int H, int rows, long long N,
+                                                       uint64_t seed, uint64_t slot0)
+{
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (m >= n) return;
+    Rng g = rng_make(seed, slot0 + (uint64_t)m, 0);
+    uint32_t w[4];
+    rng_block(g, K_INIT, 0x100u, 0, w);
+    double e0 = -s_log(u01(w[0])), e1 = -s_log(u01(w[1])), e2 = -s_log(u01(w[2]));
+    double es = (e0 + e1) + e2;
+    double Nd = (double)N;
+    long long s0 = (long long)__builtin_rint(Nd * (e0 / es));
+    long long inf = (long long)__builtin_rint(Nd * (e1 / es));
+    long long r0 = (long long)__builtin_rint(Nd * (e2 / es));
+    // first pass: the sum of the H exponentials (in index order); second pass regenerates them
+    double esum = 0.0;
+    for (int i = 0; i < H; i++) {
+        if ((i & 3) == 0) rng_block(g, K_INIT, 0x200u + (uint32_t)(i >> 2), 0, w);
+        double e = -s_log(u01(w[i & 3]));
+        esum = (i == 0) ? e : esum + e;
+    }
+    long long tot = 0;
+    int32_t lastv = 0;
+    for (int i = 0; i < H; i++) {
+        if ((i & 3) == 0) rng_block(g, K_INIT, 0x200u + (uint32_t)(i >> 2), 0, w);
+        double e = -s_log(u01(w[i & 3]));
+        int32_t v = (int32_t)__builtin_rint((double)inf * (e / esum));
+        tot += v; lastv = v;
+        out[(int64_t)(2 + i) * stride + m] = v;
+    }
+    long long left = N - (s0 + tot + r0);
+    if (s0 >= tot && s0 >= r0) s0 += left;
+    else if (tot >= r0) out[(int64_t)(2 + H - 1) * stride + m] = (int32_t)(lastv + left);
+    else r0 += left;
+    out[m] = (int32_t)s0;
+    out[stride + m] = (int32_t)r0;
+    for (int r = 2 + H; r < rows; r++) out[(int64_t)r * stride + m] = 0;
+}
+
+struct DevBuf {          // device scratch freed on scope exit
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int epi_state_rows(int H, int D) { return state_rows(H, D); }
+
+int epi_ctx_create(int device, epi_ctx** out)
+{
+    if (!out) return fail(EPI_EINVAL, "epi_ctx_create: out is NULL");
+    int ndev = 0;
+    HIPCHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(EPI_EINVAL, "epi_ctx_create: device %d not in [0, %d)", device, ndev);
+    HIPCHECK(hipSetDevice(device));
+    epi_ctx* c = new epi_ctx();
+    c->device = device;
+    HIPCHECK(hipStreamCreate(&c->stream));
+    HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
+    HIPCHECK(hipMemset(c->d_scal, 0, 256));
+    HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
+    HIPCHECK(hipEventCreate(&c->ev0));
+    HIPCHECK(hipEventCreate(&c->ev1));
+    *out = c;
+    return EPI_OK;
+}
+
+int epi_ctx_destroy(epi_ctx* c)
+{
+    if (!c) return EPI_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->d_scal) (void)hipFree(c->d_scal);
+    if (c->d_sums) (void)hipFree(c->d_sums);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return EPI_OK;
+}
+
+void* epi_ctx_stream(epi_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int epi_params_set(epi_ctx* c, const epi_params* p)
+{
+    if (!c || !p) return fail(EPI_EINVAL, "epi_params_set: NULL argument");
+    if (p->H < 1 || p->H > EPI_MAX_H) return fail(EPI_EINVAL, "epi_params_set: H = %d not in [1, %d]", p->H, EPI_MAX_H);
+    if (p->D < 0 || p->D > EPI_MAX_D) return fail(EPI_EINVAL, "epi_params_set: test_delay D = %d not in [0, %d]", p->D, EPI_MAX_D);
+    if (p->N < 1 || p->N >= (1LL << 31)) return fail(EPI_ERANGE, "epi_params_set: N = %lld must be in [1, 2^31)", (long long)p->N);
+    for (int i = 0; i < p->H; i++) {
+        if (!(p->q[i] >= 0.0 && p->q[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: q[%d] = %g not a probability", i, p->q[i]);
+        if (!(p->p[i] >= 0.0 && p->p[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: p[%d] = %g not a probability", i, p->p[i]);
+        if (!(p->k[i] >= 0.0) || !(p->theta[i] >= 0.0)) return fail(EPI_EINVAL, "epi_params_set: Gamma parameters of bin %d negative", i);
+    }
+    c->P = *p;
+    c->have_params = true;
+    return EPI_OK;
+}
+
+// ---- beliefs -----------------------------------------------------------------
+
+static int belief_check(const epi_belief* b, const char* who)
+{
+    if (!b) return fail(EPI_EINVAL, "%s: belief is NULL", who);
+    if (!b->ctx->have_params) return fail(EPI_ESTATE, "%s: epi_params_set has not been called", who);
+    if (b->rows != state_rows(b->ctx->P.H, b->ctx->P.D))
+        return fail(EPI_ESTATE, "%s: belief was created for a different (H, D)", who);
+    return EPI_OK;
+}
+
+int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief** out)
+{
+    if (!c || !out) return fail(EPI_EINVAL, "epi_belief_create: NULL argument");
+    if (!c->have_params) return fail(EPI_ESTATE, "epi_belief_create: epi_params_set has not been called");
+    if (n_local < 1 || halo_cap < 0) return fail(EPI_EINVAL, "epi_belief_create: n_local = %lld, halo_cap = %lld", (long long)n_local, (long long)halo_cap);
+    if (n_local + halo_cap >= (1LL << 31)) return fail(EPI_ERANGE, "epi_belief_create: n_local + halo_cap must be < 2^31");
+    HIPCHECK(hipSetDevice(c->device));
+    epi_belief* b = new epi_belief();
+    b->ctx = c; b->n = n_local; b->halo_cap = halo_cap;
+    b->stride = ceil_div(n_local + halo_cap, 64) * 64;          // rows start on 256-byte boundaries
+    b->n_total = n_local; b->slot0 = 0;
+    b->rows = state_rows(c->P.H, c->P.D);
+    b->nblocks = ceil_div(n_local, SCAN_TILE);
+    size_t bytes = sizeof(int32_t) * (size_t)b->rows * (size_t)b->stride;
+    hipError_t e = hipMalloc((void**)&b->buf[0], bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->buf[1], bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->anc, sizeof(int32_t) * (size_t)n_local);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)n_local);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->blocksum, sizeof(unsigned long long) * (size_t)b->nblocks);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->blocksq, sizeof(double) * (size_t)b->nblocks);
+    if (e != hipSuccess) {
+        epi_belief_destroy(b);
+        return fail(EPI_ENOMEM, "epi_belief_create: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    HIPCHECK(hipMemsetAsync(b->buf[0], 0, bytes, c->stream));
+    HIPCHECK(hipMemsetAsync(b->buf[1], 0, bytes, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *out = b;
+    return EPI_OK;
+}
+
+int epi_belief_destroy(epi_belief* b)
+{
+    if (!b) return EPI_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->buf[0]) (void)hipFree(b->buf[0]);
+    if (b->buf[1]) (void)hipFree(b->buf[1]);
+    if (b->anc) (void)hipFree(b->anc);
+    if (b->lw) (void)hipFree(b->lw);
+    if (b->blocksum) (void)hipFree(b->blocksum);
+    if (b->blocksq) (void)hipFree(b->blocksq);
+    delete b;
+    return EPI_OK;
+}
+
+int epi_belief_set_shard(epi_belief* b, int64_t n_total, int64_t slot0)
+{
+    if (!b) return fail(EPI_EINVAL, "epi_belief_set_shard: belief is NULL");
+    if (slot0 < 0 || n_total < slot0 + b->n) return fail(EPI_EINVAL, "epi_belief_set_shard: slots [%lld, %lld) not inside [0, %lld)",
+                                                         (long long)slot0, (long long)(slot0 + b->n), (long long)n_total);
+    b->n_total = n_total; b->slot0 = slot0;
+    return EPI_OK;
+}
+
+int64_t epi_belief_size(const epi_belief* b) { return b ? b->n : 0; }
+
+// fold a pending ancestor indirection into the stored particles
+static int materialize(epi_belief* b)
+{
+    if (!b->has_anc) return EPI_OK;
+    epi_ctx* c = b->ctx;
+    k_gather<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, b->anc, b->buf[b->cur ^ 1], b->rows);
+    HIPCHECK(hipGetLastError());
+    b->cur ^= 1;
+    b->has_anc = false;
+    return EPI_OK;
+}
+
+int epi_belief_upload(epi_belief* b, const int64_t* S, const int64_t* I, const int64_t* R, const int64_t* T)
+{
+    int rc = belief_check(b, "epi_belief_upload");
+    if (rc) return rc;
+    if (!S || !I || !R) return fail(EPI_EINVAL, "epi_belief_upload: S, I, R must not be NULL");
+    epi_ctx* c = b->ctx;
+    const int H = c->P.H, D = c->P.D, D1 = D + 1;
+    const int64_t n = b->n;
+    HIPCHECK(hipSetDevice(c->device));
+    std::vector<int32_t> h((size_t)b->rows * (size_t)n);
+    const int64_t lim = (1LL << 31) - 1;
+    for (int64_t p = 0; p < n; p++) {
+        if (S[p] < -lim || S[p] > lim || R[p] < 0 || R[p] > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: S or R out of int32 range", (long long)p);
+        h[(size_t)p] = (int32_t)S[p];
+        h[(size_t)n + (size_t)p] = (int32_t)R[p];
+        for (int i = 0; i < H; i++) {
+            int64_t v = I[p * H + i];
+            if (v < 0 || v > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: I[%d] = %lld out of range", (long long)p, i, (long long)v);
+            h[(size_t)(2 + i) * (size_t)n + (size_t)p] = (int32_t)v;
+        }
+        if (T) {
+            const int64_t* Tp = T + p * D1 * H;
+            for (int cidx = 0; cidx < H; cidx++)
+                for (int r = 0; r < D1; r++) {
+                    int64_t v = Tp[cidx * D1 + r];
+                    bool live = (r < D) && (cidx >= 1);
+                    if (!live) {
+                        if (v != 0) return fail(EPI_EINVAL, "epi_belief_upload: particle %lld: Tests[%d,%d] = %lld but row D+1 and column 1 must be zero",
+                                                (long long)p, r + 1, cidx + 1, (long long)v);
+                    } else {
+                        if (v < 0 || v > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: Tests entry out of range", (long long)p);
+                        h[(size_t)tests_row(H, r, cidx) * (size_t)n + (size_t)p] = (int32_t)v;
+                    }
+                }
+        } else {
+            for (int r = 2 + H; r < b->rows; r++) h[(size_t)r * (size_t)n + (size_t)p] = 0;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < b->rows; r++)
+        HIPCHECK(hipMemcpy(b->buf[b->cur] + (size_t)r * (size_t)b->stride, h.data() + (size_t)r * (size_t)n, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    b->has_anc = false;
+    b->phase = PH_IDLE;
+    return EPI_OK;
+}
+
+int epi_belief_download(epi_belief* b, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    int rc = belief_check(b, "epi_belief_download");
+    if (rc) return rc;
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_download: a phased update is in progress");
+    epi_ctx* c = b->ctx;
+    const int H = c->P.H, D = c->P.D, D1 = D + 1;
+    const int64_t n = b->n;
+    HIPCHECK(hipSetDevice(c->device));
+    rc = materialize(b);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> h((size_t)b->rows * (size_t)n);
+    for (int r = 0; r < b->rows; r++)
+        HIPCHECK(hipMemcpy(h.data() + (size_t)r * (size_t)n, b->buf[b->cur] + (size_t)r * (size_t)b->stride, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int64_t p = 0; p < n; p++) {
+        if (S) S[p] = h[(size_t)p];
+        if (R) R[p] = h[(size_t)n + (size_t)p];
+        if (I) for (int i = 0; i < H; i++) I[p * H + i] = h[(size_t)(2 + i) * (size_t)n + (size_t)p];
+        if (T) {
+            int64_t* Tp = T + p * D1 * H;
+            for (int j = 0; j < D1 * H; j++) Tp[j] = 0;
+            for (int cidx = 1; cidx < H; cidx++)
+                for (int r = 0; r < D; r++) Tp[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx) * (size_t)n + (size_t)p];
+        }
+    }
+    return EPI_OK;
+}
+
+int epi_belief_copy(epi_belief* dst, epi_belief* src)
+{
+    int rc = belief_check(src, "epi_belief_copy");
+    if (rc) return rc;
+    if (!dst || dst->n != src->n || dst->rows != src->rows || dst->stride != src->stride || dst->ctx != src->ctx)
+        return fail(EPI_EINVAL, "epi_belief_copy: beliefs differ in shape or context");
+    epi_ctx* c = src->ctx;
+    HIPCHECK(hipSetDevice(c->device));
+    size_t bytes = sizeof(int32_t) * (size_t)src->rows * (size_t)src->stride;
+    HIPCHECK(hipMemcpyAsync(dst->buf[dst->cur], src->buf[src->cur], bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dst->anc, src->anc, sizeof(int32_t) * (size_t)src->n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    dst->has_anc = src->has_anc; dst->n_total = src->n_total; dst->slot0 = src->slot0; dst->phase = PH_IDLE;
+    return EPI_OK;
+}
+
+int epi_belief_init_normal(epi_belief* b, double mu, double sigma, uint64_t seed)
+{
+    int rc = belief_check(b, "epi_belief_init_normal");
+    if (rc) return rc;
+    if (!(sigma >= 0.0)) return fail(EPI_EINVAL, "epi_belief_init_normal: sigma = %g", sigma);
+    epi_ctx* c = b->ctx;
+    HIPCHECK(hipSetDevice(c->device));
+    k_init_normal<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, c->P.H, b->rows, (long long)c->P.N, mu, sigma, seed, (uint64_t)b->slot0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->has_anc = false; b->phase = PH_IDLE;
+    return EPI_OK;
+}
+
+int epi_belief_init_simplex(epi_belief* b, uint64_t seed)
+{
+    int rc = belief_check(b, "epi_belief_init_simplex");
+    if (rc) return rc;
+    epi_ctx* c = b->ctx;
+    HIPCHECK(hipSetDevice(c->device));
+    k_init_simplex<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, c->P.H, b->rows, (long long)c->P.N, seed, (uint64_t)b->slot0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->has_anc = false; b->phase = PH_IDLE;
+    return EPI_OK;
+}
+
+// ---- the step ------------------------------------------------------------------
+
+
+static int fetch_flags(epi_ctx* c, uint32_t* flags, bool reset)
+{
+    DevScalars h;
+    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (flags) *flags = h.flags;
+    if (reset) HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+    return EPI_OK;
+}
+
+static void widen(const std::vector<int32_t>& h, int64_t n, int64_t* out) { for (int64_t i = 0; i < n; i++) out[i] = h[(size_t)i]; }
+
+int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particle, const double* a_prev, int a_prev_per_particle,
+                   uint64_t seed, uint32_t step, int64_t* o_out, double* r_out, int64_t* new_inf_out, uint32_t* flags)
+{
+    int rc = belief_check(b, "epi_step_batch");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !a) return fail(EPI_EINVAL, "epi_step_batch: bad context or NULL action");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_batch: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = b->n;
+    DevBuf da, dap, dob, dr, dni;
+    StepArgs A;
+    memset(&A, 0, sizeof A);
+    A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+    A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
+    if (a_per_particle) {
+        if (da.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(da.p, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        A.a_dev = da.as<double>();
+    }
+    A.a_prev = a_prev ? a_prev[0] : 0.0;
+    if (a_prev && a_prev_per_particle) {
+        if (dap.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(dap.p, a_prev, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        A.a_prev_dev = dap.as<double>();
+    }
+    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+    if (o_out) { if (dob.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.o_out = dob.as<int32_t>(); }
+    if (r_out) { if (dr.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.r_out = dr.as<double>(); }
+    if (new_inf_out) { if (dni.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.newinf_out = dni.as<int32_t>(); }
+    k_step<false, MODE_PHILOX><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+    HIPCHECK(hipGetLastError());
+    std::vector<int32_t> h((size_t)n);
+    if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), dob.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
+    if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), dni.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
+    if (r_out) HIPCHECK(hipMemcpyAsync(r_out, dr.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    rc = fetch_flags(c, flags, true);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->cur ^= 1; b->has_anc = false;
+    return EPI_OK;
+}
+
+int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_particle,
+                      const int64_t* sympt, const int64_t* pos, const double* gam,
+                      int64_t* new_inf_out, int64_t* pos_out, uint32_t* flags)
+{
+    int rc = belief_check(b, "epi_step_injected");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !a || !sympt || !pos || !gam) return fail(EPI_EINVAL, "epi_step_injected: NULL argument");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_injected: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = b->n;
+    const int H = c->P.H;
+    // particle-major host arrays -> one row per age bin
+    std::vector<int32_t> hs((size_t)n * H), hp((size_t)n * H);
+    std::vector<double> hg((size_t)n * H);
+    const int64_t lim = (1LL << 31) - 1;
+    for (int64_t p = 0; p < n; p++)
+        for (int i = 0; i < H; i++) {
+            int64_t s = sympt[p * H + i], q = pos[p * H + i];
+            if (s < 0 || s > lim || q < 0 || q > lim) return fail(EPI_ERANGE, "epi_step_injected: variate out of int32 range at particle %lld", (long long)p);
+            hs[(size_t)i * (size_t)n + (size_t)p] = (int32_t)s;
+            hp[(size_t)i * (size_t)n + (size_t)p] = (int32_t)q;
+            hg[(size_t)i * (size_t)n + (size_t)p] = gam[p * H + i];
+        }
+    DevBuf ds, dp, dg, da, dni, dpo;
+    size_t cnt = (size_t)n * (size_t)H;
+    if (ds.alloc(4 * cnt) != hipSuccess || dp.alloc(4 * cnt) != hipSuccess || dg.alloc(8 * cnt) != hipSuccess ||
+        dni.alloc(4 * (size_t)n) != hipSuccess || dpo.alloc(4 * cnt) != hipSuccess)
+        return fail(EPI_ENOMEM, "epi_step_injected: hipMalloc failed");
+    HIPCHECK(hipMemcpyAsync(ds.p, hs.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dp.p, hp.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dg.p, hg.data(), 8 * cnt, hipMemcpyHostToDevice, c->stream));
+    StepArgs A;
+    memset(&A, 0, sizeof A);
+    A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+    A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
+    if (a_per_particle) {
+        if (da.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_injected: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(da.p, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        A.a_dev = da.as<double>();
+    }
+    A.scal = c->d_scal; A.slot0 = (uint64_t)b->slot0;
+    A.inj_sympt = ds.as<int32_t>(); A.inj_pos = dp.as<int32_t>(); A.inj_gam = dg.as<double>();
+    A.newinf_out = dni.as<int32_t>(); A.pos_out = dpo.as<int32_t>();
+    k_step<false, MODE_INJECT><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+    HIPCHECK(hipGetLastError());
+    if (new_inf_out) {
+        std::vector<int32_t> h((size_t)n);
+        HIPCHECK(hipMemcpyAsync(h.data(), dni.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        widen(h, n, new_inf_out);
+    }
+    if (pos_out) {
+        HIPCHECK(hipMemcpyAsync(hp.data(), dpo.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t p = 0; p < n; p++)
+            for (int i = 0; i < H; i++) pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
+    }
+    rc = fetch_flags(c, flags, true);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->cur ^= 1; b->has_anc = false;
+    return EPI_OK;
+}
+
+int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32_t step,
+                      int64_t* sympt_out, int64_t* pos_out, double* gam_out, uint32_t* flags)
+{
+    int rc = belief_check(b, "epi_step_variates");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !sympt_out || !pos_out || !gam_out) return fail(EPI_EINVAL, "epi_step_variates: NULL argument");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_variates: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = b->n;
+    const int H = c->P.H;
+    const size_t cnt = (size_t)n * (size_t)H;
+    DevBuf ds, dp, dg;
+    if (ds.alloc(4 * cnt) != hipSuccess || dp.alloc(4 * cnt) != hipSuccess || dg.alloc(8 * cnt) != hipSuccess)
+        return fail(EPI_ENOMEM, "epi_step_variates: hipMalloc failed");
+    StepArgs A;
+    memset(&A, 0, sizeof A);
+    A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+    A.a = a; A.a_row_stride = 1;
+    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+    A.rec_sympt = ds.as<int32_t>(); A.rec_pos = dp.as<int32_t>(); A.rec_gam = dg.as<double>();
+    k_step<false, MODE_RECORD><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+    HIPCHECK(hipGetLastError());
+    std::vector<int32_t> hs(cnt), hp(cnt);
+    std::vector<double> hg(cnt);
+    HIPCHECK(hipMemcpyAsync(hs.data(), ds.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(hp.data(), dp.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(hg.data(), dg.p, 8 * cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int64_t p = 0; p < n; p++)
+        for (int i = 0; i < H; i++) {
+            sympt_out[p * H + i] = hs[(size_t)i * (size_t)n + (size_t)p];
+            pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
+            gam_out[p * H + i] = hg[(size_t)i * (size_t)n + (size_t)p];
+        }
+    rc = fetch_flags(c, flags, true);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->cur ^= 1; b->has_anc = false;
+    return EPI_OK;
+}
+
+int epi_sample_binomial(epi_ctx* c, int64_t count, const int64_t* n, const double* p, uint64_t seed, uint32_t step,
+                        uint32_t bin, int which, int64_t* out)
+{
+    if (!c || !n || !p || !out || count < 1 || bin > 0xffffu) return fail(EPI_EINVAL, "epi_sample_binomial: bad argument");
+    HIPCHECK(hipSetDevice(c->device));
+    std::vector<int32_t> hn((size_t)count);
+    for (int64_t j = 0; j < count; j++) {
+        if (n[j] >= (1LL << 31) || n[j] <= -(1LL << 31)) return fail(EPI_ERANGE, "epi_sample_binomial: n[%lld] out of int32 range", (long long)j);
+        hn[(size_t)j] = (int32_t)n[j];
+    }
+    DevBuf dn, dp, dout;
+    if (dn.alloc(4 * (size_t)count) != hipSuccess || dp.alloc(8 * (size_t)count) != hipSuccess || dout.alloc(4 * (size_t)count) != hipSuccess)
+        return fail(EPI_ENOMEM, "epi_sample_binomial: hipMalloc failed");
+    HIPCHECK(hipMemcpyAsync(dn.p, hn.data(), 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(dp.p, p, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(hn.data(), dout.p, 4 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int64_t j = 0; j < count; j++) out[j] = hn[(size_t)j];
+    return EPI_OK;
+}
+
+int epi_sample_gamma(epi_ctx* c, int64_t count, const double* shape, const double* scale, uint64_t seed, uint32_t step,
+                     uint32_t bin, double* out)
+{
+    if (!c || !shape || !scale || !out || count < 1 || bin > 0xffffu) return fail(EPI_EINVAL, "epi_sample_gamma: bad argument");
+    HIPCHECK(hipSetDevice(c->device));
+    DevBuf dk, ds, dout;
+    if (dk.alloc(8 * (size_t)count) != hipSuccess || ds.alloc(8 * (size_t)count) != hipSuccess || dout.alloc(8 * (size_t)count) != hipSuccess)
+        return fail(EPI_ENOMEM, "epi_sample_gamma: hipMalloc failed");
+    HIPCHECK(hipMemcpyAsync(dk.p, shape, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(ds.p, scale, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out, dout.p, 8 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
+}
+
+int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, int act_per_particle, int act_per_day, double a_prev0,
+                      uint64_t seed, uint32_t step0, int64_t* hist, double* rew, uint32_t* flags)
+{
+    int rc = belief_check(b, "epi_rollout_batch");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !actions || T < 1) return fail(EPI_EINVAL, "epi_rollout_batch: bad argument");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_rollout_batch: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = b->n;
+    const int64_t arow = act_per_day ? T : 1;
+    const size_t acount = (size_t)(act_per_particle ? n : 1) * (size_t)arow;
+    DevBuf dact, dhist, drew;
+    if (dact.alloc(sizeof(double) * acount) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed");
+    HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * acount, hipMemcpyHostToDevice, c->stream));
+    if (hist && dhist.alloc(sizeof(int32_t) * 4 * (size_t)n * (size_t)T) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed (history)");
+    if (rew && drew.alloc(sizeof(double) * (size_t)n * (size_t)T) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed (rewards)");
+    for (int t = 0; t < T; t++) {
+        StepArgs A;
+        memset(&A, 0, sizeof A);
+        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+        const int64_t tcol = act_per_day ? t : 0;
+        const int64_t pcol = act_per_day ? t - 1 : 0;          // column of the previous day's action
+        A.a_row_stride = 1;
+        if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
+        else A.a = actions[tcol];
+        if (t == 0) A.a_prev = a_prev0;                         // prev_action of the start state (typedef.jl:180,216)
+        else if (act_per_particle) { A.a_prev_dev = dact.as<double>(); A.a_prev_col = pcol; }
+        else A.a_prev = actions[pcol];
+        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+        if (hist) A.hist = dhist.as<int32_t>() + (size_t)t * 4 * (size_t)n;
+        if (rew) A.r_out = drew.as<double>() + (size_t)t * (size_t)n;
+        k_step<false, MODE_PHILOX><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+        HIPCHECK(hipGetLastError());
+        b->cur ^= 1; b->has_anc = false;
+    }
+    if (hist) {
+        std::vector<int32_t> h((size_t)4 * (size_t)n * (size_t)T);
+        HIPCHECK(hipMemcpyAsync(h.data(), dhist.p, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t p = 0; p < n; p++)
+            for (int t = 0; t < T; t++)
+                for (int k = 0; k < 4; k++) hist[(p * T + t) * 4 + k] = h[((size_t)t * 4 + (size_t)k) * (size_t)n + (size_t)p];
+    }
+    if (rew) {
+        std::vector<double> h((size_t)n * (size_t)T);
+        HIPCHECK(hipMemcpyAsync(h.data(), drew.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t p = 0; p < n; p++)
+            for (int t = 0; t < T; t++) rew[p * T + t] = h[(size_t)t * (size_t)n + (size_t)p];
+    }
+    rc = fetch_flags(c, flags, true);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
+}
+
+// ---- the filter update ---------------------------------------------------------
+
+int epi_pf_frac_bits(int64_t n_total)
+{
+    int lg = 0;
+    while (((int64_t)1 << lg) < n_total) lg++;
+    int F = 53 - lg;
+    return F > 40 ? 40 : F;
+}
+
+static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
+{
+    k_scal_reset<<<1, 1, 0, c->stream>>>(c->d_scal);
+    StepArgs A;
+    memset(&A, 0, sizeof A);
+    A.n = b->n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+    A.a = a; A.a_row_stride = 1;
+    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0;
+    A.o = (double)o; A.lw = b->lw; A.scal = c->d_scal;
+    hipEvent_t e0 = c->ev0, e1 = c->ev1;
+    if (c->timing) {
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        c->timed.emplace_back(e0, e1);
+    }
+    HIPCHECK(hipEventRecord(e0, c->stream));
+    k_step<true, MODE_PHILOX><<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventRecord(e1, c->stream));
+    if (!c->timing) c->ev_valid = true;
+    b->seed = seed; b->step = step;
+    b->halo_used = 0;
+    b->frac_bits = epi_pf_frac_bits(b->n_total);
+    return EPI_OK;
+}
+
+static int launch_weigh(epi_ctx* c, epi_belief* b)
+{
+    k_wsum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum, b->blocksq);
+    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, c->d_scal);
+    k_wcum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum);
+    HIPCHECK(hipGetLastError());
+    return EPI_OK;
+}
+
+int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
+{
+    int rc = belief_check(b, "epi_pf_update");
+    if (rc) return rc;
+    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_update: belief belongs to another context");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_update: a phased update is in progress");
+    if (b->n_total != b->n || b->slot0 != 0) return fail(EPI_ESTATE, "epi_pf_update: belief is a shard; use the phased calls");
+    HIPCHECK(hipSetDevice(c->device));
+    rc = launch_predict(c, b, a, o, seed, step);
+    if (rc) return rc;
+    k_scal_lwmax_local<<<1, 1, 0, c->stream>>>(c->d_scal);
+    rc = launch_weigh(c, b);
+    if (rc) return rc;
+    k_scal_total_local<<<1, 1, 0, c->stream>>>(c->d_scal);
+    const double u = resample_offset(seed, step);
+    k_select<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, 0, 0, reinterpret_cast<const unsigned long long*>(b->lw),
+                                                                              b->n, c->d_scal, b->n_total, u, b->anc);
+    HIPCHECK(hipGetLastError());
+    b->cur ^= 1; b->has_anc = true;
+    return EPI_OK;
+}
+
+int epi_pf_collect(epi_ctx* c, epi_belief* b, double* loglik, double* ess, uint32_t* flags)
+{
+    if (!c || !b) return fail(EPI_EINVAL, "epi_pf_collect: NULL argument");
+    HIPCHECK(hipSetDevice(c->device));
+    DevScalars h;
+    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    uint32_t f = h.flags;
+    if (h.w_total == 0ULL) f |= EPI_F_ZERO_W;
+    if (flags) *flags = f;
+    HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+    const double scale = ldexp(1.0, b->frac_bits);
+    if (loglik) *loglik = h.w_total ? h.lwmax + log((double)h.w_total / scale / (double)b->n_total) - 0.91893853320467274178 : -INFINITY;
+    if (ess) *ess = h.sumsq > 0.0 ? ((double)h.w_total * (double)h.w_total) / h.sumsq : 0.0;
+    return EPI_OK;
+}
+
+int epi_pf_update(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* loglik, double* ess, uint32_t* flags)
+{
+    int rc = epi_pf_update_async(c, b, a, o, seed, step);
+    if (rc) return rc;
+    return epi_pf_collect(c, b, loglik, ess, flags);
+}
+
+int epi_ctx_timing(epi_ctx* c, int enable)
+{
+    if (!c) return fail(EPI_EINVAL, "epi_ctx_timing: ctx is NULL");
+    c->timing = enable != 0;
+    return EPI_OK;
+}
+
+int epi_ctx_timing_read(epi_ctx* c, double* sum_ms, int64_t* count)
+{
+    if (!c) return fail(EPI_EINVAL, "epi_ctx_timing_read: ctx is NULL");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (auto& pr : c->timed) {
+        float ms = 0.0f;
+        HIPCHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (sum_ms) *sum_ms = tot;
+    if (count) *count = (int64_t)c->timed.size();
+    c->timed.clear();
+    return EPI_OK;
+}
+
+float epi_last_predict_ms(epi_ctx* c)
+{
+    if (!c || !c->ev_valid) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---- phased update for sharded populations ---------------------------------------
+
+int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* lwmax_local)
+{
+    int rc = belief_check(b, "epi_pf_predict");
+    if (rc) return rc;
+    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_predict: belief belongs to another context");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict: previous update not finished");
+    HIPCHECK(hipSetDevice(c->device));
+    rc = launch_predict(c, b, a, o, seed, step);
+    if (rc) return rc;
+    DevScalars h;
+    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (lwmax_local) *lwmax_local = h.lwmax_bits ? order_decode(h.lwmax_bits) : -INFINITY;
+    b->phase = PH_PREDICTED;
+    return EPI_OK;
+}
+
+int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_local, double* sumsq_local)
+{
+    int rc = belief_check(b, "epi_pf_weigh");
+    if (rc) return rc;
+    if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh: call epi_pf_predict first");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipMemcpyAsync(&c->d_scal->lwmax, &lwmax_global, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    rc = launch_weigh(c, b);
+    if (rc) return rc;
+    DevScalars h;
+    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (w_local) *w_local = h.w_local;
+    if (sumsq_local) *sumsq_local = h.sumsq;
+    b->phase = PH_WEIGHED;
+    return EPI_OK;
+}
+
+static inline int64_t shard_start(int64_t n_total, int G, int g) { return (int64_t)(((__int128)n_total * g) / G); }
+
+int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, uint32_t step, int64_t* lo)
+{
+    if (n_total < 1 || G < 1 || !w_shard || !lo) return fail(EPI_EINVAL, "epi_pf_plan: bad argument");
+    uint64_t W = 0;
+    for (int g = 0; g < G; g++) W += w_shard[g];
+    if (W == 0) {                       // nothing to resample: every shard keeps its own slots
+        for (int g = 0; g <= G; g++) lo[g] = shard_start(n_total, G, g);
+        return EPI_OK;
+    }
+    const double u = resample_offset(seed, step);
+    const double stepw = (double)W / (double)n_total;
+    uint64_t off = 0;
+    lo[0] = 0;
+    for (int g = 1; g < G; g++) {
+        off += w_shard[g - 1];
+        // first slot m with floor(fl(fl(m + u) * stepw)) >= off
+        double guess = ceil((double)off / stepw - u);
+        int64_t m = guess < 0.0 ? 0 : (guess > (double)n_total ? n_total : (int64_t)guess);
+        auto tq = [&](int64_t mm) { return (uint64_t)floor(((double)mm + u) * stepw); };
+        while (m > 0 && tq(m - 1) >= off) m--;
+        while (m < n_total && tq(m) < off) m++;
+        lo[g] = m;
+    }
+    lo[G] = n_total;
+    return EPI_OK;
+}
+
+static int set_offsets(epi_ctx* c, int G, int shard, const uint64_t* w_shard)
+{
+    unsigned long long v[2] = {0ULL, 0ULL};     // w_off, w_total
+    for (int g = 0; g < G; g++) { if (g < shard) v[0] += w_shard[g]; v[1] += w_shard[g]; }
+    HIPCHECK(hipMemcpyAsync(&c->d_scal->w_off, v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
+}
+
+int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
+                        int64_t slot_begin, int64_t slot_end)
+{
+    int rc = belief_check(b, "epi_pf_select_local");
+    if (rc) return rc;
+    if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_select_local: call epi_pf_weigh first");
+    if (slot_begin < b->slot0 || slot_end > b->slot0 + b->n || slot_begin > slot_end)
+        return fail(EPI_EINVAL, "epi_pf_select_local: slots [%lld, %lld) not owned by this shard", (long long)slot_begin, (long long)slot_end);
+    if (slot_begin == slot_end) return EPI_OK;
+    HIPCHECK(hipSetDevice(c->device));
+    rc = set_offsets(c, G, shard, w_shard);
+    if (rc) return rc;
+    const double u = resample_offset(seed, step);
+    const int64_t count = slot_end - slot_begin;
+    k_select<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin, b->slot0, reinterpret_cast<const unsigned long long*>(b->lw),
+                                                                             b->n, c->d_scal, b->n_total, u, b->anc);
+    HIPCHECK(hipGetLastError());
+    return EPI_OK;
+}
+
+int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
+                  int64_t slot_begin, int64_t slot_end, void* dev_buf)
+{
+    int rc = belief_check(b, "epi_pf_export");
+    if (rc) return rc;
+    if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_export: call epi_pf_weigh first");
+    if (slot_begin > slot_end || slot_begin < 0 || slot_end > b->n_total || !dev_buf) return fail(EPI_EINVAL, "epi_pf_export: bad slot range or NULL buffer");
+    if (slot_begin == slot_end) return EPI_OK;
+    HIPCHECK(hipSetDevice(c->device));
+    rc = set_offsets(c, G, shard, w_shard);
+    if (rc) return rc;
+    const double u = resample_offset(seed, step);
+    const int64_t count = slot_end - slot_begin;
+    // the propagated particles of this update live in the buffer k_step wrote
+    k_export<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin, b->slot0, reinterpret_cast<const unsigned long long*>(b->lw),
+                                                                             b->n, c->d_scal, b->n_total, u, b->buf[b->cur ^ 1], b->stride, b->rows,
+                                                                             static_cast<int32_t*>(dev_buf));
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
+}
+
+int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
+{
+    int rc = belief_check(b, "epi_pf_import");
+    if (rc) return rc;
+    if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_import: call epi_pf_weigh first");
+    if (slot_begin < b->slot0 || slot_end > b->slot0 + b->n || slot_begin > slot_end || !dev_buf)
+        return fail(EPI_EINVAL, "epi_pf_import: slots [%lld, %lld) not owned by this shard", (long long)slot_begin, (long long)slot_end);
+    const int64_t count = slot_end - slot_begin;
+    if (count == 0) return EPI_OK;
+    if (b->halo_used + count > b->halo_cap) return fail(EPI_ERANGE, "epi_pf_import: halo capacity %lld exceeded", (long long)b->halo_cap);
+    HIPCHECK(hipSetDevice(c->device));
+    k_import<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin - b->slot0, b->n + b->halo_used, static_cast<const int32_t*>(dev_buf),
+                                                                             b->buf[b->cur ^ 1], b->stride, b->rows, b->anc);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->halo_used += count;
+    return EPI_OK;
+}
+
+int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
+{
+    int rc = belief_check(b, "epi_pf_finish");
+    if (rc) return rc;
+    if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_finish: no update in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    rc = fetch_flags(c, flags, true);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    b->cur ^= 1; b->has_anc = true; b->phase = PH_IDLE;
+    return EPI_OK;
+}
+
+// ---- summaries ---------------------------------------------------------------------
+
+int epi_belief_sums(epi_ctx* c, epi_belief* b, int64_t* sums)
+{
+    int rc = belief_check(b, "epi_belief_sums");
+    if (rc) return rc;
+    if (!sums) return fail(EPI_EINVAL, "epi_belief_sums: sums is NULL");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_sums: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int H = c->P.H, D = c->P.D, D1 = D + 1;
+    HIPCHECK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * (size_t)b->rows, c->stream));
+    int64_t gx = ceil_div(b->n, TPB);
+    if (gx > 1024) gx = 1024;
+    k_sums<<<dim3((unsigned)gx, (unsigned)b->rows), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->d_sums);
+    HIPCHECK(hipGetLastError());
+    std::vector<long long> h((size_t)b->rows);
+    HIPCHECK(hipMemcpyAsync(h.data(), c->d_sums, sizeof(long long) * (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    sums[0] = h[0]; sums[1] = h[1];
+    for (int i = 0; i < H; i++) sums[2 + i] = h[(size_t)(2 + i)];
+    int64_t* ts = sums + 2 + H;
+    for (int j = 0; j < D1 * H; j++) ts[j] = 0;
+    for (int cidx = 1; cidx < H; cidx++)
+        for (int r = 0; r < D; r++) ts[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx)];
+    return EPI_OK;
+}
+
+static inline int64_t div_round_half_even(int64_t s, int64_t n) { return (int64_t)nearbyint((double)s / (double)n); }
+
+int epi_mean_from_sums(const epi_params* p, int64_t n_total, const int64_t* sums, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    if (!p || !sums || !S || !I || !R || n_total < 1) return fail(EPI_EINVAL, "epi_mean_from_sums: bad argument");
+    const int H = p->H, D1 = p->D + 1;
+    *S = div_round_half_even(sums[0], n_total);                       // updater.jl:15
+    int64_t tot = 0;
+    for (int i = 0; i < H; i++) { I[i] = div_round_half_even(sums[2 + i], n_total); tot += I[i]; }   // :16
+    *R = p->N - (*S + tot);                                           // :17
+    if (T) for (int j = 0; j < D1 * H; j++) T[j] = div_round_half_even(sums[2 + H + j], n_total);     // :19
+    if (*R < 0) return fail(EPI_EINVAL, "epi_mean_from_sums: mean R = %lld < 0 (src/updater.jl:18 asserts)", (long long)*R);
+    return EPI_OK;
+}
+
+int epi_belief_mean(epi_ctx* c, epi_belief* b, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    int64_t sums[2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H];
+    int rc = epi_belief_sums(c, b, sums);
+    if (rc) return rc;
+    return epi_mean_from_sums(&c->P, b->n, sums, S, I, R, T);
+}
+
+int epi_belief_sample(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    int rc = belief_check(b, "epi_belief_sample");
+    if (rc) return rc;
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_sample: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int H = c->P.H, D = c->P.D, D1 = D + 1;
+    Rng g = rng_make(seed, ctr, 0);
+    uint32_t w[4];
+    rng_block(g, K_INIT, 0x300u, 0, w);
+    uint64_t r53 = (((uint64_t)(w[0] >> 5)) << 26) | (uint64_t)(w[1] >> 6);
+    int64_t slot = (int64_t)(((__int128)r53 * b->n) >> 53);
+    int32_t col = (int32_t)slot;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (b->has_anc) HIPCHECK(hipMemcpy(&col, b->anc + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> h((size_t)b->rows);
+    HIPCHECK(hipMemcpy2D(h.data(), sizeof(int32_t), b->buf[b->cur] + col, sizeof(int32_t) * (size_t)b->stride, sizeof(int32_t), (size_t)b->rows, hipMemcpyDeviceToHost));
+    if (S) *S = h[0];
+    if (R) *R = h[1];
+    if (I) for (int i = 0; i < H; i++) I[i] = h[(size_t)(2 + i)];
+    if (T) {
+        for (int j = 0; j < D1 * H; j++) T[j] = 0;
+        for (int cidx = 1; cidx < H; cidx++)
+            for (int r = 0; r < D; r++) T[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx)];
+    }
+    return EPI_OK;
+}
+
+} // extern "C"

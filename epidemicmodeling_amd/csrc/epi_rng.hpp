@@ -1,0 +1,308 @@
+// Counter-based random variates for the gfx950 particle kernels.
+//
+// Every variate is a pure function of (seed, global particle slot, step,
+// stream tag, attempt): a Philox4x32-10 block addressed by
+//   key     = (seed lo, seed hi)
+//   counter = (slot lo, slot hi, step, kind << 24 | bin << 8 | blk)
+// so results do not depend on launch geometry, sharding or execution order.
+//
+// The elementary functions below are written as explicit sequences of IEEE-754
+// operations (compile with -ffp-contract=off; fma only where written) so that
+// a host restatement of the same sequence reproduces every accept/reject
+// decision bit for bit.  No device-library transcendental is used.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace epi {
+
+// stream kinds (the tag's top byte)
+constexpr uint32_t K_BINOM0 = 0u;  // words 0,1: isolation draw attempt 0; words 2,3: positive-test draw attempt 0
+constexpr uint32_t K_SYMPT  = 1u;  // blk j: isolation attempts 1+2j (words 0,1) and 2+2j (words 2,3)
+constexpr uint32_t K_POS    = 2u;  // same for the positive-test draw
+constexpr uint32_t K_GAMMA  = 3u;  // blk j: attempts 2j (normal 0, word 2) and 2j+1 (normal 1, word 3)
+constexpr uint32_t K_BOOST  = 4u;  // word 0: uniform of the shape<1 boost
+constexpr uint32_t K_RESAMP = 5u;  // slot 0: words 0,1 -> 53-bit systematic-resampling offset
+constexpr uint32_t K_INIT   = 6u;  // initial-state generators
+
+#define EPI_HD __host__ __device__ __forceinline__
+
+EPI_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
+EPI_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
+EPI_HD uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+EPI_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+struct Rng {
+    uint32_t k0, k1, c0, c1, c2;
+};
+
+EPI_HD Rng rng_make(uint64_t seed, uint64_t slot, uint32_t step)
+{
+    Rng g;
+    g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32);
+    g.c0 = (uint32_t)slot; g.c1 = (uint32_t)(slot >> 32); g.c2 = step;
+    return g;
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).
+EPI_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                          uint32_t k0, uint32_t k1, uint32_t (&w)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+
+EPI_HD void rng_block(const Rng& g, uint32_t kind, uint32_t bin, uint32_t blk, uint32_t (&w)[4])
+{
+    philox4x32_10(g.c0, g.c1, g.c2, (kind << 24) | (bin << 8) | blk, g.k0, g.k1, w);
+}
+
+// uniform in (0,1): (w + 1/2) 2^-32, exact in binary64
+EPI_HD double u01(uint32_t w) { return ((double)w + 0.5) * 0x1p-32; }
+
+// ---- elementary functions ---------------------------------------------------
+
+// natural log, x > 0 finite normal; argument reduction to [sqrt(1/2), sqrt(2))
+// and the degree-14 series in s = f/(2+f) of the classic fdlibm scheme.
+EPI_HD double s_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t ix = d2u(x);
+    int e = (int)(ix >> 52) - 1023;
+    double m = u2d((ix & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double hfsq = (0.5 * f) * f;
+    double dk = (double)e;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// exp(x) for x <= ~700; exactly 0 below -708 (and for NaN / -inf)
+EPI_HD double s_exp(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    if (!(x >= -708.0)) return 0.0;
+    if (x > 709.0) x = 709.0;
+    double kd = __builtin_floor(__builtin_fma(x, 1.4426950408889634, 0.5));
+    double r = __builtin_fma(-kd, ln2_hi, x);
+    r = __builtin_fma(-kd, ln2_lo, r);
+    double p = 1.6059043836821613e-10;
+    p = __builtin_fma(p, r, 2.08767569878681e-09);
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 0.0001984126984126984);
+    p = __builtin_fma(p, r, 0.001388888888888889);
+    p = __builtin_fma(p, r, 0.008333333333333333);
+    p = __builtin_fma(p, r, 0.041666666666666664);
+    p = __builtin_fma(p, r, 0.16666666666666666);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    int k = (int)kd;
+    return p * u2d((uint64_t)(k + 1023) << 52);
+}
+
+// binary32 log for x in (0, 1]
+EPI_HD float s_logf(float x)
+{
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
+    uint32_t ix = f2u(x);
+    int e = (int)(ix >> 23) - 127;
+    float m = u2f((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float w = z * z;
+    float t1 = w * __builtin_fmaf(w, Lg4, Lg2);
+    float t2 = z * __builtin_fmaf(w, Lg3, Lg1);
+    float R = t2 + t1;
+    float hfsq = (0.5f * f) * f;
+    float dk = (float)e;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// Box-Muller in binary32: two words -> two standard normals.  The angle is
+// (quadrant + 1/2) pi/2 + ph with |ph| <= pi/4, so sin/cos need only short
+// polynomials and one rotation by 45 degrees.
+EPI_HD void box_muller(uint32_t w0, uint32_t w1, float& z0, float& z1)
+{
+    float u1 = __builtin_fmaf((float)w0, 0x1p-32f, 0x1p-33f);   // (0, 1]
+    float r = __builtin_sqrtf(-2.0f * s_logf(u1));
+    uint32_t quad = w1 >> 30;
+    int32_t ti = (int32_t)(w1 & 0x3fffffffu) - (1 << 29);
+    float y = ((float)ti + 0.5f) * 0x1p-30f;                    // [-1/2, 1/2]
+    float ph = y * 1.57079637f;
+    float x2 = ph * ph;
+    float sp = ph * __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, 2.7557319e-06f, -0.0001984127f), 0.008333334f), -0.16666667f), 1.0f);
+    float cp = __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, -2.755732e-07f, 2.4801588e-05f), -0.0013888889f), 0.041666668f), -0.5f), 1.0f);
+    float h = r * 0.70710677f;
+    float a = cp * h, b = sp * h;
+    float c = a - b, s = a + b;
+    // rotate (c, s) by quad * 90 degrees
+    float zc = (quad & 1u) ? s : c;
+    float zs = (quad & 1u) ? c : s;
+    if (quad == 1u || quad == 2u) zc = -zc;
+    if (quad >= 2u) zs = -zs;
+    z0 = zc; z1 = zs;
+}
+
+// ---- Binomial(n, p) -----------------------------------------------------------
+// n * min(p, 1-p) < 10 : sequential inversion from 0 (one uniform)
+// otherwise            : transformed rejection with squeeze (Hoermann 1993, BTRS)
+
+EPI_HD double stirling_tail(double k)
+{
+    // log(k!) - [ (k + 1/2) log(k+1) - (k+1) + log(sqrt(2 pi)) ]
+    if (k <= 9.0) {
+        int i = (int)k;
+        double t = 0.08106146679532726;
+        t = (i == 1) ? 0.04134069595540929 : t;
+        t = (i == 2) ? 0.02767792568499834 : t;
+        t = (i == 3) ? 0.02079067210376509 : t;
+        t = (i == 4) ? 0.01664469118982119 : t;
+        t = (i == 5) ? 0.01387612882307075 : t;
+        t = (i == 6) ? 0.01189670994589177 : t;
+        t = (i == 7) ? 0.01041126526197209 : t;
+        t = (i == 8) ? 0.009255462182712733 : t;
+        t = (i == 9) ? 0.008330563433362871 : t;
+        return t;
+    }
+    double kp1 = k + 1.0;
+    double kp1sq = kp1 * kp1;
+    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / kp1;
+}
+
+constexpr uint32_t BINOM_MAX_ATTEMPTS = 512u;
+
+// fa, fb: the attempt-0 word pair; attempts a >= 1 come from blocks of retry_kind.
+EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
+                             const Rng& g, uint32_t retry_kind, uint32_t bin)
+{
+    if (n <= 0 || !(p > 0.0)) return 0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    const double pp = flip ? 1.0 - p : p;
+    const double qq = 1.0 - pp;
+    const double nd = (double)n;
+    int32_t x;
+    if (nd * pp < 10.0) {
+        double s = pp / qq;
+        double a = (nd + 1.0) * s;
+        double r = s_exp(nd * s_log(qq));
+        double u = u01(fa);
+        x = 0;
+        while (u > r && x < n) {
+            u -= r;
+            x += 1;
+            r *= (a / (double)x - s);
+        }
+    } else {
+        double spq = __builtin_sqrt(nd * pp * qq);
+        double b = 1.15 + 2.53 * spq;
+        double a = -0.0873 + 0.0248 * b + 0.01 * pp;
+        double c = nd * pp + 0.5;
+        double vr = 0.92 - 4.2 / b;
+        double alpha = (2.83 + 5.1 / b) * spq;
+        double r = pp / qq;
+        double m = __builtin_floor((nd + 1.0) * pp);
+        x = (int32_t)m;
+        uint32_t w[4] = {fa, fb, 0u, 0u};
+        for (uint32_t att = 0; att < BINOM_MAX_ATTEMPTS; att++) {
+            uint32_t wa, wb;
+            if (att == 0) { wa = fa; wb = fb; }
+            else {
+                uint32_t half = (att - 1u) & 1u;
+                if (half == 0u) rng_block(g, retry_kind, bin, (att - 1u) >> 1, w);
+                wa = half ? w[2] : w[0];
+                wb = half ? w[3] : w[1];
+            }
+            double u = u01(wa) - 0.5;
+            double v = u01(wb);
+            double us = 0.5 - __builtin_fabs(u);
+            double kd = __builtin_floor((2.0 * a / us + b) * u + c);
+            if (kd < 0.0 || kd > nd) continue;
+            if (us >= 0.07 && v <= vr) { x = (int32_t)kd; break; }
+            double lv = s_log(v * alpha / (a / (us * us) + b));
+            double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
+                      + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
+                      + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
+                      + stirling_tail(m) + stirling_tail(nd - m)
+                      - stirling_tail(kd) - stirling_tail(nd - kd);
+            if (lv <= ub) { x = (int32_t)kd; break; }
+        }
+    }
+    return flip ? n - x : x;
+}
+
+// ---- Gamma(shape, scale) --------------------------------------------------------
+// Marsaglia-Tsang (2000); shape < 1 boosted by U^(1/shape); shape < 2^-30 -> 0.
+constexpr uint32_t GAMMA_MAX_ATTEMPTS = 512u;
+
+EPI_HD double gamma_draw(double shape, double scale, const Rng& g, uint32_t bin)
+{
+    if (!(shape >= 0x1p-30)) return 0.0;
+    const bool boost = shape < 1.0;
+    const double al = boost ? shape + 1.0 : shape;
+    const double d = al - 0.3333333333333333;
+    const double c = 1.0 / __builtin_sqrt(9.0 * d);
+    double v = 1.0;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    float z0 = 0.f, z1 = 0.f;
+    for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
+        if ((att & 1u) == 0u) {
+            rng_block(g, K_GAMMA, bin, att >> 1, w);
+            box_muller(w[0], w[1], z0, z1);
+        }
+        double x = (double)((att & 1u) ? z1 : z0);
+        double u = u01((att & 1u) ? w[3] : w[2]);
+        double t = 1.0 + c * x;
+        if (!(t > 0.0)) continue;
+        double vv = t * t * t;
+        double x2 = x * x;
+        if (u < 1.0 - 0.0331 * (x2 * x2)) { v = vv; break; }
+        if (s_log(u) < 0.5 * x2 + d * (1.0 - vv + s_log(vv))) { v = vv; break; }
+    }
+    double gval = d * v;
+    if (boost) {
+        uint32_t wb[4];
+        rng_block(g, K_BOOST, bin, 0, wb);
+        gval = gval * s_exp(s_log(u01(wb[0])) / shape);
+    }
+    return gval * scale;
+}
+
+// 53-bit uniform in [0,1) of the systematic resampler for (seed, step)
+EPI_HD double resample_offset(uint64_t seed, uint32_t step)
+{
+    Rng g = rng_make(seed, 0, step);
+    uint32_t w[4];
+    rng_block(g, K_RESAMP, 0, 0, w);
+    uint64_t hi = w[0] >> 5, lo = w[1] >> 6;
+    return (double)((hi << 26) | lo) * 0x1p-53;
+}
+
+} // namespace epi

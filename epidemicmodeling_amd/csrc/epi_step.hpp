@@ -1,0 +1,201 @@
+// One InfectionSim step of one particle, streamed bin by bin over the
+// struct-of-arrays device state.
+//
+// Reference semantics (WhiffleFish/EpidemicModeling):
+//   src/simulate.jl:53-61   SymptomaticIsolation
+//   src/simulate.jl:73-82   PositiveTests
+//   src/simulate.jl:99-129  UpdateIsolations
+//   src/simulate.jl:137-151 SimStep
+//   src/simulate.jl:37-45   incident_infections, src/init.jl:71-78 RVsum
+//   src/simulate.jl:153-158 reward
+//   src/POMDPsInterface.jl:11-23 observation (moments from the pre-step state)
+//
+// Device state layout: int32 rows of `stride` elements, one element per
+// particle (struct of arrays):
+//   row 0            S
+//   row 1            R
+//   rows 2 .. 2+H-1  I[age]
+//   rows 2+H ..      pending tests that carry across steps, only for
+//                    test_delay D >= 1: reference Tests[r, c] for r = 1..D,
+//                    c = 2..H at row 2 + H + (r-1)(H-1) + (c-2).
+// Row D+1 and column 1 of the reference Tests matrix are always zero between
+// steps (simulate.jl:125-126), so they are not stored.
+//
+// The step is evaluated per age bin with no per-thread arrays, so H and D are
+// run-time values.  Floating-point sums whose order matters for the integer
+// results (the infection sum of simulate.jl:38-41, the moment sums of
+// POMDPsInterface.jl:19-20) are accumulated in the reference's index order.
+#pragma once
+#include "epi_rng.hpp"
+#include "../../include/epi.h"
+
+namespace epi {
+
+__host__ __device__ __forceinline__ int state_rows(int H, int D) { return 2 + H + D * (H - 1); }
+__host__ __device__ __forceinline__ int tests_row(int H, int r0, int c0) { return 2 + H + r0 * (H - 1) + (c0 - 1); }  // r0 in [0,D), c0 in [1,H)
+
+// Variates from the Philox streams of one (slot, step).
+struct PhiloxDraws {
+    Rng g;
+    __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double q, int32_t n_tested, double p,
+                                               int32_t& sympt, int32_t& pos) const
+    {
+        uint32_t w[4];
+        rng_block(g, K_BINOM0, (uint32_t)bin, 0, w);
+        sympt = binomial_draw(n_inf, q, w[0], w[1], g, K_SYMPT, (uint32_t)bin);
+        pos = binomial_draw(n_tested, p, w[2], w[3], g, K_POS, (uint32_t)bin);
+    }
+    __device__ __forceinline__ double gamma(int bin, double shape, double scale) const
+    {
+        return gamma_draw(shape, scale, g, (uint32_t)bin);
+    }
+};
+
+// Philox variates that are also written out (rows of n elements per age bin),
+// so that another implementation of the step can be driven by the same draws.
+struct RecordingDraws {
+    Rng g; int32_t* sympt; int32_t* pos; double* gam; int64_t n; int64_t idx;
+    __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double q, int32_t n_tested, double p,
+                                               int32_t& s, int32_t& ps) const
+    {
+        PhiloxDraws d{g};
+        d.binomials(bin, n_inf, q, n_tested, p, s, ps);
+        sympt[(int64_t)bin * n + idx] = s;
+        pos[(int64_t)bin * n + idx] = ps;
+    }
+    __device__ __forceinline__ double gamma(int bin, double shape, double scale) const
+    {
+        double v = gamma_draw(shape, scale, g, (uint32_t)bin);
+        gam[(int64_t)bin * n + idx] = v;
+        return v;
+    }
+};
+
+// Variates supplied by the caller: rows of n elements per age bin.
+struct InjectedDraws {
+    const int32_t* sympt; const int32_t* pos; const double* gam; int64_t n; int64_t idx;
+    __device__ __forceinline__ void binomials(int bin, int32_t, double, int32_t, double, int32_t& s, int32_t& p) const
+    {
+        s = sympt[(int64_t)bin * n + idx];
+        p = pos[(int64_t)bin * n + idx];
+    }
+    __device__ __forceinline__ double gamma(int bin, double, double) const { return gam[(int64_t)bin * n + idx]; }
+};
+
+struct StepResult {
+    int32_t new_inf;
+    int32_t o;          // sum of positive tests
+    int32_t sum_inf;    // sum of I after the step
+    double mu, var;     // observation moments of the PRE-step state
+    uint32_t flags;
+};
+
+struct BinOut { int32_t ipost; double mean, sd2; };
+
+// Process one age bin (0-based column i) of the isolation update.  Writes the
+// shifted pending-test rows of column i+1 and returns I_i after isolation.
+template <class Draws>
+__device__ __forceinline__ BinOut process_bin(const epi_params& P, int i, const int32_t* __restrict__ in, int64_t in_stride, int64_t src,
+                                              int32_t* __restrict__ out, int64_t out_stride, int64_t dst,
+                                              double a, const Draws& draws, int32_t& R, int32_t& o_sum, uint32_t& flags,
+                                              int32_t* __restrict__ pos_out, int64_t pos_stride)
+{
+    const int H = P.H, D = P.D;
+    int32_t Ii = in[(int64_t)(2 + i) * in_stride + src];
+    int32_t already = 0;
+    if (D > 0 && i >= 1)
+        for (int r = 0; r < D; r++) already += in[(int64_t)tests_row(H, r, i) * in_stride + src];
+    double ntf = __builtin_floor((double)(Ii - already) * a);                  // simulate.jl:78
+    int32_t nt = (int32_t)ntf;
+    if (nt < 0) flags |= EPI_F_NEG_NT;
+    const double pi = P.p[i];
+    int32_t sympt, pos;
+    draws.binomials(i, Ii, P.q[i], nt, pi, sympt, pos);                         // simulate.jl:58, :79
+    BinOut bo;
+    bo.mean = ntf * pi;                                                        // POMDPsInterface.jl:19
+    double sd = __builtin_sqrt(ntf * pi * (1.0 - pi));
+    bo.sd2 = sd * sd;                                                          // POMDPsInterface.jl:20
+    double pr = (double)sympt / (double)Ii;                                    // simulate.jl:104
+    if (pr != pr) pr = 0.0;                                                    // simulate.jl:105
+    const double om = 1.0 - pr;
+    R += sympt; Ii -= sympt;                                                   // simulate.jl:107-108
+    // column i of the tests matrix after :110 and :112; row 0 leaves the pipeline (:114-115),
+    // rows 1..D move to rows 0..D-1 of column i+1 (:122), column H wraps to column 1 and is cleared (:125)
+    for (int r = 0; r <= D; r++) {
+        int32_t tv;
+        if (r == D) tv = pos;
+        else tv = (i >= 1) ? in[(int64_t)tests_row(H, r, i) * in_stride + src] : 0;
+        int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
+        if (r == 0) { R += ts; Ii -= ts; }
+        else if (i + 1 < H) out[(int64_t)tests_row(H, r - 1, i + 1) * out_stride + dst] = ts;
+    }
+    if (Ii < 0) flags |= EPI_F_NEG_I;                                          // simulate.jl:117
+    o_sum += pos;
+    if (pos_out) pos_out[(int64_t)i * pos_stride + dst] = pos;
+    bo.ipost = Ii;
+    return bo;
+}
+
+// Full step of the particle stored at column `src` of `in`, written to column
+// `dst` of `out`.
+template <class Draws>
+__device__ __forceinline__ StepResult particle_step(const epi_params& P, const int32_t* __restrict__ in, int64_t in_stride, int64_t src,
+                                                    int32_t* __restrict__ out, int64_t out_stride, int64_t dst,
+                                                    double a, const Draws& draws,
+                                                    int32_t* __restrict__ pos_out, int64_t pos_stride)
+{
+    const int H = P.H;
+    StepResult res;
+    res.flags = 0; res.o = 0;
+    int32_t S = in[src];
+    int32_t R = in[in_stride + src];
+    // the last age bin first: its survivors recover (simulate.jl:144) and, through the
+    // circular shift of simulate.jl:145, seed the first term of the infection sum
+    BinOut last = process_bin(P, H - 1, in, in_stride, src, out, out_stride, dst, a, draws, R, res.o, res.flags, pos_out, pos_stride);
+    R += last.ipost;
+    double infsum = draws.gamma(0, P.k[0] * (double)last.ipost, P.theta[0]);   // simulate.jl:40, init.jl:71-78
+    int32_t sum_inf = 0;
+    double tm = 0.0, tv = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < H - 1; i++) {
+        BinOut bo = process_bin(P, i, in, in_stride, src, out, out_stride, dst, a, draws, R, res.o, res.flags, pos_out, pos_stride);
+        tm += bo.mean; tv += bo.sd2;
+        out[(int64_t)(2 + i + 1) * out_stride + dst] = bo.ipost;               // simulate.jl:145
+        sum_inf += bo.ipost;
+        infsum += draws.gamma(i + 1, P.k[i + 1] * (double)bo.ipost, P.theta[i + 1]);
+    }
+    tm += last.mean; tv += last.sd2;
+    int64_t denom = P.N - (int64_t)R;
+    int32_t newi = 0;
+    if (denom <= 0) res.flags |= EPI_F_BAD_DENOM;
+    else {
+        double sprop = (double)S / (double)denom;                              // simulate.jl:42
+        newi = (int32_t)__builtin_floor(sprop * infsum);                       // simulate.jl:44
+    }
+    out[(int64_t)2 * out_stride + dst] = newi;                                 // simulate.jl:147
+    out[dst] = S - newi;                                                       // simulate.jl:148
+    out[out_stride + dst] = R;
+    res.new_inf = newi;
+    res.sum_inf = sum_inf + newi;
+    res.mu = tm; res.var = tv;
+    return res;
+}
+
+// log weight up to the constant -log(sqrt(2 pi)); a degenerate Normal(mu, 0)
+// gives 0 at o == mu and -inf elsewhere.
+__device__ __forceinline__ double log_weight(double mu, double var, double od)
+{
+    if (!(var > 0.0)) return (od == mu) ? 0.0 : -__builtin_inf();
+    double dlt = od - mu;
+    return -0.5 * (dlt * dlt / var) - 0.5 * s_log(var);
+}
+
+__device__ __forceinline__ double reward_of(const epi_params& P, int32_t sum_inf, double a, double a_prev)
+{
+    double inf_loss = P.inf_loss * (double)sum_inf / (double)P.N;
+    double test_loss = P.test_loss * a;
+    double rate_loss = P.testrate_loss * __builtin_fabs(a - a_prev);
+    return -(inf_loss + test_loss + rate_loss);
+}
+
+} // namespace epi

@@ -1,0 +1,389 @@
+"""Host interface over the gfx950 library, shaped like the reference's
+POMDPs.jl / ParticleFilters.jl surface (src/POMDPsInterface.jl, src/updater.jl,
+src/simulate.jl of WhiffleFish/EpidemicModeling):
+
+    gen(pomdp, s, a)                     POMDPs.gen            POMDPsInterface.jl:1-9
+    observation(pomdp, s, a, sp)         POMDPs.observation    POMDPsInterface.jl:11-23
+    BootstrapFilter(pomdp, n)            ParticleFilters       POMDPsInterface.jl:39
+    update(upd, b, a, o)                 ParticleFilters       POMDPsInterface.jl:56
+    ParticleCollection / n_particles / particles / rand
+    initialbelief(pomdp, np)             updater.jl:1-3
+    mean(pc, pomdp)                      updater.jl:5-25
+    Simulate(T, state, params, action)   simulate.jl:175-196
+    SimulateEnsemble(T, n, params, a)    simulate.jl:210-227
+    Simulate(T, state, b, pomdp, planner) POMDPsInterface.jl:29-62
+
+Every particle operation runs in libepi_gfx950.so; nothing here computes a
+step or a weight on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64p, as_i64p, check
+from .params import Action, CovidPOMDP, State, unity_test_period
+
+_DEFAULT_SEED = 0x5EED
+
+
+class Context:
+    """One device + stream + installed parameters (epi_ctx)."""
+
+    def __init__(self, pomdp: CovidPOMDP, device: int = 0):
+        self.lib = _lib.load()
+        self.pomdp = pomdp
+        self._h = C.c_void_p()
+        check(self.lib.epi_ctx_create(device, C.byref(self._h)))
+        self._cparams = pomdp.to_c()
+        check(self.lib.epi_params_set(self._h, C.byref(self._cparams)))
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self.lib.epi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def context_for(pomdp: CovidPOMDP, device: int = 0) -> Context:
+    key = (pomdp, device)
+    if key not in _contexts:
+        _contexts[key] = Context(pomdp, device)
+    return _contexts[key]
+
+
+def _flatten_states(pomdp: CovidPOMDP, states: Sequence[State]):
+    H, D1 = pomdp.horizon, pomdp.test_delay + 1
+    n = len(states)
+    S = np.fromiter((s.S for s in states), dtype=np.int64, count=n)
+    R = np.fromiter((s.R for s in states), dtype=np.int64, count=n)
+    I = np.empty((n, H), dtype=np.int64)
+    T = np.empty((n, H, D1), dtype=np.int64)      # column-major (D+1) x H per particle
+    for j, s in enumerate(states):
+        if s.I.shape != (H,) or s.Tests.shape != (D1, H):
+            raise ValueError("state shape does not match the model's horizon / test_delay")
+        I[j] = s.I
+        T[j] = s.Tests.T
+    return S, np.ascontiguousarray(I), R, np.ascontiguousarray(T)
+
+
+def _unflatten_states(pomdp: CovidPOMDP, S, I, R, T, prev_action: Action) -> List[State]:
+    return [State(int(S[j]), I[j].copy(), int(R[j]), T[j].T.copy(), prev_action) for j in range(len(S))]
+
+
+class ParticleCollection:
+    """A belief: n particles resident on the device (ParticleCollection{State}).
+
+    Value semantics: update() returns a new collection only if asked to
+    (copy=True); by default the update is in place, because at 10^8 particles a
+    history of beliefs (SimHist.beliefs, src/simulate.jl:21) does not fit."""
+
+    def __init__(self, ctx: Context, n: int, halo_cap: int = 0):
+        self.ctx = ctx
+        self.n = int(n)
+        self._h = C.c_void_p()
+        self.prev_action = Action(0.0)
+        check(ctx.lib.epi_belief_create(ctx.handle, self.n, int(halo_cap), C.byref(self._h)))
+
+    # -- construction ------------------------------------------------------
+    @classmethod
+    def from_states(cls, pomdp: CovidPOMDP, states: Sequence[State], device: int = 0) -> "ParticleCollection":
+        ctx = context_for(pomdp, device)
+        b = cls(ctx, len(states))
+        b.upload(*_flatten_states(pomdp, states))
+        if states:
+            b.prev_action = states[0].prev_action
+        return b
+
+    def upload(self, S, I, R, T=None):
+        S = np.ascontiguousarray(S, dtype=np.int64)
+        I = np.ascontiguousarray(I, dtype=np.int64)
+        R = np.ascontiguousarray(R, dtype=np.int64)
+        T = None if T is None else np.ascontiguousarray(T, dtype=np.int64)
+        H, D1 = self.ctx.pomdp.horizon, self.ctx.pomdp.test_delay + 1
+        if S.shape != (self.n,) or R.shape != (self.n,) or I.size != self.n * H or (T is not None and T.size != self.n * H * D1):
+            raise ValueError("array sizes do not match the belief")
+        check(self.ctx.lib.epi_belief_upload(self._h, as_i64p(S), as_i64p(I), as_i64p(R), as_i64p(T)))
+
+    def download(self):
+        """(S[n], I[n,H], R[n], T[n,H,D+1]) as int64 host arrays."""
+        H, D1 = self.ctx.pomdp.horizon, self.ctx.pomdp.test_delay + 1
+        S = np.empty(self.n, dtype=np.int64)
+        R = np.empty(self.n, dtype=np.int64)
+        I = np.empty((self.n, H), dtype=np.int64)
+        T = np.empty((self.n, H, D1), dtype=np.int64)
+        check(self.ctx.lib.epi_belief_download(self._h, as_i64p(S), as_i64p(I), as_i64p(R), as_i64p(T)))
+        return S, I, R, T
+
+    def copy(self) -> "ParticleCollection":
+        out = ParticleCollection(self.ctx, self.n)
+        check(self.ctx.lib.epi_belief_copy(out._h, self._h))
+        out.prev_action = self.prev_action
+        return out
+
+    @property
+    def particles(self) -> List[State]:
+        return _unflatten_states(self.ctx.pomdp, *self.download(), self.prev_action)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.epi_belief_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def n_particles(b: ParticleCollection) -> int:
+    return b.n
+
+
+def particles(b: ParticleCollection) -> List[State]:
+    return b.particles
+
+
+def rand(b: ParticleCollection, seed: int = _DEFAULT_SEED, ctr: int = 0) -> State:
+    """rand(rng, b): one particle uniformly at random."""
+    p = b.ctx.pomdp
+    H, D1 = p.horizon, p.test_delay + 1
+    S, R = C.c_int64(), C.c_int64()
+    I = np.empty(H, dtype=np.int64)
+    T = np.empty((H, D1), dtype=np.int64)
+    check(b.ctx.lib.epi_belief_sample(b.ctx.handle, b.handle, seed, ctr, C.byref(S), as_i64p(I), C.byref(R), as_i64p(T)))
+    return State(S.value, I, R.value, T.T.copy(), b.prev_action)
+
+
+def initialbelief(pomdp: CovidPOMDP, np_: int, mu: float = 10_000.0, sigma: float = 5_000.0, seed: int = _DEFAULT_SEED,
+                  device: int = 0) -> ParticleCollection:
+    """initialbelief(pomdp, np) (src/updater.jl:1-3) with initialstate(pomdp)
+    = State(Normal(mu, sigma), pomdp) as in test/POMCPOWtest.jl:8-10; particles
+    are generated on the device."""
+    b = ParticleCollection(context_for(pomdp, device), np_)
+    check(b.ctx.lib.epi_belief_init_normal(b.handle, mu, sigma, seed))
+    return b
+
+
+def random_states(pomdp: CovidPOMDP, n: int, seed: int = _DEFAULT_SEED, device: int = 0) -> ParticleCollection:
+    """n draws of State(params) (src/typedef.jl:196-217) generated on the device."""
+    b = ParticleCollection(context_for(pomdp, device), n)
+    check(b.ctx.lib.epi_belief_init_simplex(b.handle, seed))
+    return b
+
+
+# ---------------------------------------------------------------------------
+# generative model
+# ---------------------------------------------------------------------------
+def step_batch(b: ParticleCollection, a, a_prev=None, seed: int = _DEFAULT_SEED, step: int = 0,
+               want_o: bool = True, want_r: bool = True):
+    """continuous_gen (src/simulate.jl:160-166) over all particles of b, in place.
+    a / a_prev: a float or an array of n floats.  Returns (o[n], r[n], flags)."""
+    n = b.n
+    a_arr = np.ascontiguousarray(np.atleast_1d(np.asarray(a, dtype=np.float64)))
+    per = int(a_arr.size == n and n > 1) if a_arr.size != 1 else 0
+    if a_arr.size not in (1, n):
+        raise ValueError("a must be a scalar or have one entry per particle")
+    if a_prev is None:
+        a_prev = b.prev_action.testing_prop
+    ap_arr = np.ascontiguousarray(np.atleast_1d(np.asarray(a_prev, dtype=np.float64)))
+    if ap_arr.size not in (1, n):
+        raise ValueError("a_prev must be a scalar or have one entry per particle")
+    pper = int(ap_arr.size == n and n > 1) if ap_arr.size != 1 else 0
+    o = np.empty(n, dtype=np.int64) if want_o else None
+    r = np.empty(n, dtype=np.float64) if want_r else None
+    flags = C.c_uint32(0)
+    check(b.ctx.lib.epi_step_batch(b.ctx.handle, b.handle, as_f64p(a_arr), per, as_f64p(ap_arr), pper, seed, step,
+                                   as_i64p(o), as_f64p(r), None, C.byref(flags)))
+    if a_arr.size == 1:
+        b.prev_action = Action(float(a_arr[0]))
+    return o, r, flags.value
+
+
+def gen(pomdp: CovidPOMDP, s: State, a: Action, seed: int = _DEFAULT_SEED, step: int = 0, device: int = 0):
+    """POMDPs.gen(pomdp, s, a, rng) (src/POMDPsInterface.jl:1-9): test_period
+    sub-steps under one action; returns (sp, o of the LAST sub-step, summed r).
+    Sub-step i uses stream step * test_period + i."""
+    b = ParticleCollection.from_states(pomdp, [s], device)
+    rsum, o = 0.0, 0
+    for i in range(pomdp.test_period):
+        ov, rv, _ = step_batch(b, a.testing_prop, seed=seed, step=step * pomdp.test_period + i)
+        o, rsum = int(ov[0]), rsum + float(rv[0])
+    sp = b.particles[0]
+    b.close()
+    return sp, o, rsum
+
+
+def observation(pomdp: CovidPOMDP, s: State, a: Action, sp: Optional[State] = None):
+    """POMDPs.observation (src/POMDPsInterface.jl:11-23): (mean, std) of the
+    Normal that moment-matches the sum of per-age Binomials, computed from the
+    pre-step state s.  Host arithmetic on one state (used by planners); the
+    filter computes the same moments on the device for every particle."""
+    tot_mean, tot_var = 0.0, 0.0
+    for i in range(pomdp.horizon):
+        already = int(s.Tests[:, i].sum())
+        nt = float(np.floor((int(s.I[i]) - already) * a.testing_prop))
+        p = pomdp.pos_test_probs[i]
+        tot_mean += nt * p
+        tot_var += float(np.sqrt(nt * p * (1 - p))) ** 2
+    return tot_mean, float(np.sqrt(tot_var))
+
+
+# ---------------------------------------------------------------------------
+# the bootstrap filter
+# ---------------------------------------------------------------------------
+@dataclass
+class BootstrapFilter:
+    """BootstrapFilter(pomdp, n) (ParticleFilters.jl; src/POMDPsInterface.jl:39)."""
+    pomdp: CovidPOMDP
+    n: int
+    seed: int = _DEFAULT_SEED
+    step: int = 0                      # advanced by every update
+    last_loglik: float = float("nan")
+    last_ess: float = float("nan")
+    last_flags: int = 0
+
+
+def update(upd: BootstrapFilter, b: ParticleCollection, a: Action, o: int, copy: bool = False) -> ParticleCollection:
+    """update(upd, b, a, o): predict, weight by the observation likelihood,
+    systematic resample (src/POMDPsInterface.jl:56).  In place unless copy=True."""
+    if b.n != upd.n:
+        raise ValueError("belief size differs from the filter's particle count")
+    if copy:
+        b = b.copy()
+    ll, ess, flags = C.c_double(), C.c_double(), C.c_uint32()
+    check(b.ctx.lib.epi_pf_update(b.ctx.handle, b.handle, a.testing_prop, int(o), upd.seed, upd.step,
+                                  C.byref(ll), C.byref(ess), C.byref(flags)))
+    upd.step += 1
+    upd.last_loglik, upd.last_ess, upd.last_flags = ll.value, ess.value, flags.value
+    b.prev_action = a
+    return b
+
+
+def mean(b: ParticleCollection, pomdp: Optional[CovidPOMDP] = None) -> State:
+    """mean(pc, pomdp) (src/updater.jl:5-25)."""
+    p = b.ctx.pomdp
+    H, D1 = p.horizon, p.test_delay + 1
+    S, R = C.c_int64(), C.c_int64()
+    I = np.empty(H, dtype=np.int64)
+    T = np.empty((H, D1), dtype=np.int64)
+    check(b.ctx.lib.epi_belief_mean(b.ctx.handle, b.handle, C.byref(S), as_i64p(I), C.byref(R), as_i64p(T)))
+    return State(S.value, I, R.value, T.T.copy(), b.prev_action)
+
+
+# ---------------------------------------------------------------------------
+# rollouts
+# ---------------------------------------------------------------------------
+@dataclass
+class SimHist:
+    """src/simulate.jl:12-22"""
+    sus: np.ndarray
+    inf: np.ndarray
+    rec: np.ndarray
+    N: int
+    T: int
+    pos_test: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))
+    actions: list = field(default_factory=list)
+    rewards: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    beliefs: list = field(default_factory=list)
+
+    def Array(self) -> np.ndarray:
+        """3 x T (src/simulate.jl:28-30)"""
+        return np.stack([self.sus, self.inf, self.rec])
+
+
+def rollout_batch(b: ParticleCollection, T: int, actions, seed: int = _DEFAULT_SEED, step0: int = 0,
+                  want_hist: bool = True, want_rew: bool = True):
+    """T days over every particle of b (in place).  actions: scalar, [T], [n] or [n, T].
+    Returns hist int64[n, T, 4] (S, sum I, R before the day; sum(pos) of the day), rew[n, T], flags."""
+    n = b.n
+    act = np.asarray(actions, dtype=np.float64)
+    if act.ndim == 0:
+        per_p, per_d, act = 0, 0, act.reshape(1)
+    elif act.ndim == 1 and act.size == T and not (act.size == n and n != T):
+        per_p, per_d = 0, 1
+    elif act.ndim == 1 and act.size == n:
+        per_p, per_d = 1, 0
+    elif act.ndim == 2 and act.shape == (n, T):
+        per_p, per_d = 1, 1
+    else:
+        raise ValueError("actions must be a scalar, [T], [n] or [n, T]")
+    act = np.ascontiguousarray(act)
+    hist = np.empty((n, T, 4), dtype=np.int64) if want_hist else None
+    rew = np.empty((n, T), dtype=np.float64) if want_rew else None
+    flags = C.c_uint32()
+    check(b.ctx.lib.epi_rollout_batch(b.ctx.handle, b.handle, T, as_f64p(act), per_p, per_d, b.prev_action.testing_prop,
+                                      seed, step0, as_i64p(hist), as_f64p(rew), C.byref(flags)))
+    return hist, rew, flags.value
+
+
+def Simulate(T: int, state: State, params: CovidPOMDP, action: Action, seed: int = _DEFAULT_SEED, device: int = 0) -> SimHist:
+    """Simulate(T, state, params, action) (src/simulate.jl:175-196)."""
+    b = ParticleCollection.from_states(params, [state], device)
+    hist, rew, _ = rollout_batch(b, T, action.testing_prop, seed=seed)
+    b.close()
+    h = hist[0]
+    return SimHist(h[:, 0].copy(), h[:, 1].copy(), h[:, 2].copy(), params.N, T, h[:, 3].copy(), [action] * T, rew[0].copy())
+
+
+def SimulateEnsemble(T: int, trajectories: int, params: CovidPOMDP, action, seed: int = _DEFAULT_SEED,
+                     device: int = 0) -> np.ndarray:
+    """SimulateEnsemble (src/simulate.jl:210-227) followed by Array(::Vector{SimHist})
+    (src/simulate.jl:291-297): int64[3, T, trajectories] from random State(params)
+    starts.  action: one Action or a sequence of `trajectories` Actions."""
+    b = random_states(params, trajectories, seed=seed, device=device)
+    if isinstance(action, Action):
+        acts = action.testing_prop
+    else:
+        acts = np.array([a.testing_prop for a in action], dtype=np.float64)
+        if acts.size != trajectories:
+            raise ValueError("need one action per trajectory")
+    hist, _, _ = rollout_batch(b, T, acts, seed=seed, step0=1, want_rew=False)
+    b.close()
+    return np.ascontiguousarray(np.transpose(hist[:, :, :3], (2, 1, 0)))
+
+
+def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: CovidPOMDP,
+                       planner: Callable[[ParticleCollection], Action], seed: int = _DEFAULT_SEED,
+                       keep_beliefs: bool = False) -> SimHist:
+    """Simulate(T, state, b, pomdp, planner) (src/POMDPsInterface.jl:29-62):
+    plan every test_period days, step the true state, update the belief."""
+    single = unity_test_period(pomdp)
+    upd = BootstrapFilter(single, n_particles(b), seed=seed)
+    sus, inf, rec = (np.zeros(T, dtype=np.int64) for _ in range(3))
+    tests = np.zeros(T, dtype=np.int64)
+    rewards = np.zeros(T)
+    actions: List[Action] = []
+    beliefs = []
+    for day in range(T):
+        action = planner(b) if day % pomdp.test_period == 0 else actions[day - 1]
+        sus[day], inf[day], rec[day] = state.S, int(state.I.sum()), state.R
+        actions.append(action)
+        if keep_beliefs:
+            beliefs.append(b.copy())
+        state, o, r = gen(single, state, action, seed=seed ^ 0x7275E, step=day)
+        b = update(upd, b, action, o)
+        rewards[day], tests[day] = r, o
+    return SimHist(sus, inf, rec, pomdp.N, T, tests, actions, rewards, beliefs)

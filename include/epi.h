@@ -1,0 +1,236 @@
+/*
+ * epi.h -- C ABI of libepi_gfx950.so: the InfectionSim particle step and the
+ * bootstrap particle-filter belief update on AMD Instinct MI355X (gfx950).
+ *
+ * This is the boundary a host in any language binds (Julia `ccall`, Python
+ * ctypes, C/C++).  Plain C types only.  Every entry point names the piece of
+ * the reference (WhiffleFish/EpidemicModeling, paths relative to its checkout)
+ * whose work it takes over.
+ *
+ * Conventions
+ *   - return value 0 = success, negative EPI_E* = failure; epi_last_error()
+ *     returns a message for the last failure on the calling thread.
+ *   - the caller owns every host array; the library owns device memory behind
+ *     the opaque epi_ctx / epi_belief handles until *_destroy.
+ *   - calls are synchronous unless stated (they return after the device work
+ *     has completed); a context is not thread-safe.
+ *   - host state layout = a Julia Vector{State} flattened:
+ *       S[n], R[n]        int64
+ *       I[n*H]            int64, particle p / age i at p*H + i
+ *       T[n*(D+1)*H]      int64, per particle the column-major (D+1) x H Tests
+ *                         matrix (row r, col c at p*(D+1)*H + c*(D+1) + r);
+ *                         may be NULL (= all zero)
+ *     Counts are narrowed to int32 on the device: N must be < 2^31.  Tests row
+ *     D+1 and column 1 must be zero (they always are between SimStep calls,
+ *     src/simulate.jl:125-126).
+ *   - random variates are pure functions of (seed, global particle slot, step):
+ *     see epi_rng.hpp.  `step` distinguishes successive calls; reuse of a
+ *     (seed, step) pair reproduces the same draws.
+ */
+#ifndef EPI_H
+#define EPI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPI_MAX_H 64   /* infection-age bins */
+#define EPI_MAX_D 7    /* test_delay */
+
+/* status codes */
+#define EPI_OK          0
+#define EPI_EINVAL     -1   /* bad argument (message says which)                  */
+#define EPI_EHIP       -2   /* a HIP runtime call failed                          */
+#define EPI_ENOMEM     -3   /* device or host allocation failed                   */
+#define EPI_ERANGE     -4   /* a count does not fit the device representation     */
+#define EPI_ESTATE     -5   /* call made in the wrong phase of an update          */
+
+/* per-step condition flags (bit set, returned through `flags` arguments) */
+#define EPI_F_NEG_I      1u /* an I[age] went negative (src/simulate.jl:117 assert) */
+#define EPI_F_NEG_NT     2u /* a tested count was negative                          */
+#define EPI_F_BAD_DENOM  4u /* N - R <= 0 in incident_infections (simulate.jl:42)   */
+#define EPI_F_ZERO_W     8u /* every particle weight was zero: particles kept       */
+
+/* Model parameters the step needs: the numeric content of the reference's
+ * CovidPOMDP struct (src/typedef.jl:43-56) after its constructor has run
+ * (src/typedef.jl:78-116).
+ *   q[i]     = (F(i+1) - F(i)) (1 - asymptomatic_prob) symptomatic_isolation_prob,
+ *              F = cdf(symptom_dist)                      (src/simulate.jl:56-57)
+ *   p[i]     = pos_test_probs[i+1]                        (src/simulate.jl:79)
+ *   k, theta = params(Infdistributions[i+1])              (src/init.jl:72) */
+typedef struct epi_params {
+    int32_t H;              /* horizon = length(Infdistributions)        */
+    int32_t D;              /* test_delay                                 */
+    int64_t N;              /* population                                 */
+    double inf_loss, test_loss, testrate_loss;
+    double q[EPI_MAX_H];
+    double p[EPI_MAX_H];
+    double k[EPI_MAX_H];
+    double theta[EPI_MAX_H];
+} epi_params;
+
+typedef struct epi_ctx epi_ctx;         /* one device, one stream, the parameters */
+typedef struct epi_belief epi_belief;   /* a set of particles resident in HBM     */
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Bind a context to HIP device `device` (creates a stream and scalar scratch). */
+int epi_ctx_create(int device, epi_ctx **out);
+int epi_ctx_destroy(epi_ctx *ctx);
+/* Install the model parameters (replaces passing `params::CovidPOMDP` to every
+ * call: src/simulate.jl:137, src/POMDPsInterface.jl:1). */
+int epi_params_set(epi_ctx *ctx, const epi_params *p);
+const char *epi_last_error(void);
+/* Number of int32 rows of the device state for (H, D): 2 + H + D (H - 1). */
+int epi_state_rows(int H, int D);
+
+/* ---- beliefs (ParticleCollection{State}, src/updater.jl:1-3) -------------- */
+
+/* n_local particles on this device; halo_cap extra columns for particles
+ * received from other shards (0 for a single-device belief). */
+int epi_belief_create(epi_ctx *ctx, int64_t n_local, int64_t halo_cap, epi_belief **out);
+int epi_belief_destroy(epi_belief *b);
+/* Place this belief in a sharded population: it holds global slots
+ * [slot0, slot0 + n_local) of n_total.  Default: slot0 = 0, n_total = n_local. */
+int epi_belief_set_shard(epi_belief *b, int64_t n_total, int64_t slot0);
+int64_t epi_belief_size(const epi_belief *b);
+/* Host <-> device transfer in the host layout above (ParticleCollection(particles),
+ * particles(b)).  Download resolves pending resampling indirection first. */
+int epi_belief_upload(epi_belief *b, const int64_t *S, const int64_t *I, const int64_t *R, const int64_t *T);
+int epi_belief_download(epi_belief *b, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+/* Copy src into dst (same shape): beliefs have value semantics in the reference
+ * (beliefHist[day] = b, src/POMDPsInterface.jl:53). */
+int epi_belief_copy(epi_belief *dst, epi_belief *src);
+
+/* Initial particles generated on the device.
+ * epi_belief_init_normal: State(Normal(mu, sigma), params) per particle
+ *   (src/typedef.jl:159-181; the stale test/POMCPOWtest.jl:8-10 initialstate).
+ * epi_belief_init_simplex: State(params) per particle (src/typedef.jl:196-217). */
+int epi_belief_init_normal(epi_belief *b, double mu, double sigma, uint64_t seed);
+int epi_belief_init_simplex(epi_belief *b, uint64_t seed);
+
+/* ---- the stochastic step ---------------------------------------------------- */
+
+/* continuous_gen over every particle of b (src/simulate.jl:160-166 wrapping
+ * SimStep, src/simulate.jl:137-151): b <- sp.  a / a_prev: one value
+ * (per_particle = 0) or n_local values.  Optional host outputs, n_local each:
+ * o = sum(pos_tests), r = reward (src/simulate.jl:153-158), new_inf. */
+int epi_step_batch(epi_ctx *ctx, epi_belief *b,
+                   const double *a, int a_per_particle, const double *a_prev, int a_prev_per_particle,
+                   uint64_t seed, uint32_t step,
+                   int64_t *o_out, double *r_out, int64_t *new_inf_out, uint32_t *flags);
+
+/* SimStep with the 3H variates of every particle supplied by the caller
+ * (sympt, pos: int64[n*H]; gam: double[n*H]; particle-major), i.e. the
+ * deterministic bookkeeping of src/simulate.jl:99-151 alone.  pos_out: int64[n*H]. */
+int epi_step_injected(epi_ctx *ctx, epi_belief *b, const double *a, int a_per_particle,
+                      const int64_t *sympt, const int64_t *pos, const double *gam,
+                      int64_t *new_inf_out, int64_t *pos_out, uint32_t *flags);
+
+/* One step of every particle of b (as epi_step_batch with one action) that also
+ * returns the 3H variates each particle drew (sympt, pos: int64[n*H]; gam:
+ * double[n*H]; particle-major): the three `rand` calls of src/simulate.jl:40,58,79.
+ * A harness feeds them to the reference's own SimStep to compare counts. */
+int epi_step_variates(epi_ctx *ctx, epi_belief *b, double a, uint64_t seed, uint32_t step,
+                      int64_t *sympt_out, int64_t *pos_out, double *gam_out, uint32_t *flags);
+
+/* The bare samplers the step uses (rand(Binomial(n, p)), src/simulate.jl:58,79;
+ * rand(Gamma(shape, scale)), src/simulate.jl:40 with src/init.jl:71-78), one
+ * draw per element; element j uses the streams of particle slot j, age bin
+ * `bin`; which = 0: the isolation draw's words, 1: the positive-test draw's. */
+int epi_sample_binomial(epi_ctx *ctx, int64_t count, const int64_t *n, const double *p, uint64_t seed, uint32_t step,
+                        uint32_t bin, int which, int64_t *out);
+int epi_sample_gamma(epi_ctx *ctx, int64_t count, const double *shape, const double *scale, uint64_t seed, uint32_t step,
+                     uint32_t bin, double *out);
+
+/* Simulate / SimulateEnsemble (src/simulate.jl:175-227): T days from the
+ * particles of b, which end at day T.  actions: [n or 1][T or 1] doubles.
+ * hist (optional): int64[n][T][4] = S, sum(I), R before each day's step and
+ * sum(pos_tests) of the day; rew (optional): double[n][T]. */
+int epi_rollout_batch(epi_ctx *ctx, epi_belief *b, int T,
+                      const double *actions, int act_per_particle, int act_per_day, double a_prev0,
+                      uint64_t seed, uint32_t step0,
+                      int64_t *hist, double *rew, uint32_t *flags);
+
+/* ---- the bootstrap filter update ---------------------------------------------- */
+
+/* update(BootstrapFilter(pomdp, n), b, a, o) (ParticleFilters.jl; call sites
+ * src/POMDPsInterface.jl:39,56 and src/MPC.jl:363,393): predict every
+ * particle through SimStep, weight by pdf(observation(pomdp, s, a, sp), o)
+ * (src/POMDPsInterface.jl:11-23), systematic resample to n particles.  b <- b'.
+ * loglik (optional): log of the mean particle likelihood; ess (optional):
+ * effective sample size of the weights. */
+int epi_pf_update(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step,
+                  double *loglik, double *ess, uint32_t *flags);
+
+/* The same update in phases, for a population sharded over several devices
+ * (one process per device; the caller exchanges the small results between
+ * phases, e.g. with torch.distributed / RCCL):
+ *   1. epi_pf_predict : fused weight + step of the local particles;
+ *                       returns the local maximum log weight.
+ *   2. epi_pf_weigh   : fixed-point weights relative to the GLOBAL maximum and
+ *                       their local prefix sums; returns the local weight total
+ *                       and sum of squares.  frac_bits = epi_pf_frac_bits(n_total).
+ *   3. epi_pf_plan    : given the weight totals of all G shards, the global
+ *                       output-slot range [lo[g], lo[g+1]) whose ancestors live
+ *                       in shard g (host arithmetic, identical on every rank).
+ *   4. epi_pf_select_local : ancestors for the part of that range this shard
+ *                       also owns (no data movement);
+ *      epi_pf_export  : for a part owned by another shard, the resampled
+ *                       particles themselves, packed as int32[rows][count];
+ *      epi_pf_import  : place a packed block received from another shard.
+ *   5. epi_pf_finish  : close the update (swap buffers, collect flags). */
+int epi_pf_frac_bits(int64_t n_total);
+int epi_pf_predict(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step, double *lwmax_local);
+int epi_pf_weigh(epi_ctx *ctx, epi_belief *b, double lwmax_global, uint64_t *w_local, double *sumsq_local);
+int epi_pf_plan(int64_t n_total, int n_shards, const uint64_t *w_shard, uint64_t seed, uint32_t step,
+                int64_t *lo /* n_shards + 1 */);
+int epi_pf_select_local(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const uint64_t *w_shard,
+                        uint64_t seed, uint32_t step, int64_t slot_begin, int64_t slot_end);
+int epi_pf_export(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const uint64_t *w_shard,
+                  uint64_t seed, uint32_t step, int64_t slot_begin, int64_t slot_end, void *dev_buf);
+int epi_pf_import(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t slot_end, const void *dev_buf);
+int epi_pf_finish(epi_ctx *ctx, epi_belief *b, uint32_t *flags);
+
+/* ---- belief summaries ------------------------------------------------------- */
+
+/* Integer column sums over the particles of b: sums[0] = sum S, sums[1] = sum R,
+ * sums[2 .. 2+H) = sum I[age], then the (D+1) x H column-major sums of Tests.
+ * The sharded mean adds these over shards before rounding. */
+int epi_belief_sums(epi_ctx *ctx, epi_belief *b, int64_t *sums /* 2 + H + (D+1) H */);
+/* mean(pc, pomdp) (src/updater.jl:5-25): sums / n rounded half to even,
+ * R = N - (S + sum I); returns EPI_EINVAL if that R is negative (the
+ * reference asserts). */
+int epi_belief_mean(epi_ctx *ctx, epi_belief *b, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+int epi_mean_from_sums(const epi_params *p, int64_t n_total, const int64_t *sums,
+                       int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+/* rand(rng, b): one particle, uniformly (src/updater.jl:2 pattern; POMCPOW
+ * samples states from the belief). */
+int epi_belief_sample(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr,
+                      int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+
+/* ---- introspection for benchmarks ------------------------------------------- */
+/* The context's HIP stream (hipStream_t) so that callers can bracket work with
+ * their own events. */
+void *epi_ctx_stream(epi_ctx *ctx);
+/* Asynchronous variant of epi_pf_update: enqueues the whole update on the
+ * context's stream and returns without synchronising; diagnostics stay on the
+ * device until epi_pf_collect. */
+int epi_pf_update_async(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step);
+int epi_pf_collect(epi_ctx *ctx, epi_belief *b, double *loglik, double *ess, uint32_t *flags);
+/* With timing enabled every filter update brackets its fused step kernel with a
+ * pair of HIP events on the context's stream; epi_ctx_timing_read waits for the
+ * stream, returns the summed kernel time (ms) and the number of launches since
+ * the last read, and clears the list. */
+int epi_ctx_timing(epi_ctx *ctx, int enable);
+int epi_ctx_timing_read(epi_ctx *ctx, double *sum_ms, int64_t *count);
+/* Time of the fused predict kernel of the last update, measured with HIP events
+ * on the context's stream (milliseconds); negative if unavailable. */
+float epi_last_predict_ms(epi_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPI_H */

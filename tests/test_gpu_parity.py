@@ -1,0 +1,362 @@
+"""Parity of the HIP path (through the C ABI of libepi_gfx950.so) with the CPU
+oracle on the same seeded inputs.  Integer results are compared bit for bit;
+the only floating-point outputs (rewards, log-likelihood, ESS) to the stated
+tolerances.  PARITY UNPINNED: the oracle is this build's restatement of the
+reference (no reference outputs exist); see oracle/epi_oracle.c."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import random_states, reference_test_params
+import epidemicmodeling_amd as em
+from epidemicmodeling_amd import _lib
+from epidemicmodeling_amd._lib import as_f64p, as_i64p, check
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+def _belief(pomdp, st):
+    b = em.ParticleCollection(em.interface.context_for(pomdp), len(st[0]))
+    b.upload(*st)
+    return b
+
+
+def _eq(dev, ref):
+    for name, x, y in zip("SIRT", dev, ref):
+        assert x.shape == y.shape and (x == y).all(), f"{name} differs at {np.argwhere(x != y)[:5].tolist()}"
+
+
+# ---------------------------------------------------------------------------
+# samplers
+# ---------------------------------------------------------------------------
+def test_binomial_sampler_bit_exact():
+    pomdp = em.make_pomdp(LOD=5)
+    ctx = em.interface.context_for(pomdp)
+    L = pyoracle.lib()
+    rng = np.random.default_rng(0)
+    cnt = 200_000
+    n = np.concatenate([rng.integers(0, 50, cnt // 4), rng.integers(0, 5000, cnt // 4), rng.integers(0, 2_000_000, cnt // 4),
+                        rng.integers(0, 2 ** 31 - 1, cnt // 4)]).astype(np.int64)
+    p = rng.random(cnt)
+    p[::7] = rng.random(len(p[::7])) * 1e-4
+    p[::11] = 1 - rng.random(len(p[::11])) * 1e-3
+    p[::101] = 0.0
+    p[::103] = 1.0
+    for which in (0, 1):
+        out = np.empty(cnt, np.int64)
+        check(ctx.lib.epi_sample_binomial(ctx.handle, cnt, as_i64p(n), as_f64p(p), 99, 7, 5, which, as_i64p(out)))
+        ref = np.array([L.orc_binomial(99, j, 7, 5, which, int(n[j]), float(p[j])) for j in range(cnt)], dtype=np.int64)
+        bad = np.flatnonzero(out != ref)
+        assert bad.size == 0, (bad[:5], n[bad[:5]], p[bad[:5]], out[bad[:5]], ref[bad[:5]])
+
+
+def test_gamma_sampler_bit_exact():
+    pomdp = em.make_pomdp(LOD=5)
+    ctx = em.interface.context_for(pomdp)
+    L = pyoracle.lib()
+    rng = np.random.default_rng(1)
+    cnt = 200_000
+    shape = np.concatenate([rng.random(cnt // 4), rng.random(cnt // 4) * 20, 10.0 ** rng.uniform(1, 7, cnt // 4),
+                            10.0 ** rng.uniform(-12, 0, cnt // 4)])
+    shape[::97] = 0.0
+    scale = 10.0 ** rng.uniform(-3, 1, cnt)
+    out = np.empty(cnt)
+    check(ctx.lib.epi_sample_gamma(ctx.handle, cnt, as_f64p(shape), as_f64p(scale), 4242, 3, 9, as_f64p(out)))
+    ref = np.array([L.orc_gamma(4242, j, 3, 9, float(shape[j]), float(scale[j])) for j in range(cnt)])
+    bad = np.flatnonzero(out.view(np.uint64) != ref.view(np.uint64))
+    assert bad.size == 0, (bad[:5], shape[bad[:5]], out[bad[:5]], ref[bad[:5]])
+
+
+# ---------------------------------------------------------------------------
+# the step
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("delay", [0, 1, 5])
+def test_step_injected_bit_exact(delay):
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    rng = np.random.default_rng(10 + delay)
+    n, H = 5000, pomdp.horizon
+    st = random_states(pomdp, n, rng)
+    a = rng.random(n)
+    a[::10] = 0.0
+    a[1::10] = 1.0
+    S, I, R, T = st
+    sympt = np.floor(rng.random((n, H)) * 0.3 * I).astype(np.int64)
+    nt = np.floor((I - T.sum(axis=2)).astype(np.float64) * a[:, None]).astype(np.int64)
+    pos = np.floor(rng.random((n, H)) * np.maximum(nt, 0)).astype(np.int64)
+    gam = rng.gamma(2.0, 50.0, size=(n, H)) * (rng.random((n, H)) > 0.2)
+    b = _belief(pomdp, st)
+    ni = np.empty(n, np.int64); po = np.empty((n, H), np.int64); fl = C.c_uint32()
+    check(b.ctx.lib.epi_step_injected(b.ctx.handle, b.handle, as_f64p(a), 1, as_i64p(sympt), as_i64p(pos), as_f64p(gam),
+                                      as_i64p(ni), as_i64p(po), C.byref(fl)))
+    exp, eni, epo, efl = orc.step_injected(st, a, sympt, pos, gam)
+    _eq(b.download(), exp)
+    assert (ni == eni).all() and (po == epo).all() and fl.value == efl
+
+
+@pytest.mark.parametrize("pidx", range(6))
+def test_step_batch_bit_exact(pidx):
+    pomdp = reference_test_params()[pidx]
+    orc = pyoracle.Oracle(pomdp.to_c())
+    rng = np.random.default_rng(20 + pidx)
+    n = 3000
+    scale = [30, 3000, 20000][pidx % 3]
+    st = random_states(pomdp, n, rng, scale=scale)
+    a = rng.random(n)
+    a_prev = rng.random(n)
+    b = _belief(pomdp, st)
+    o, r, fl = em.step_batch(b, a, a_prev, seed=SEED + pidx, step=3)
+    exp, eo, er, eni, efl = orc.step_batch(st, a, a_prev, seed=SEED + pidx, step=3)
+    _eq(b.download(), exp)
+    assert (o == eo).all() and fl == efl
+    assert (r.view(np.uint64) == er.view(np.uint64)).all()          # same IEEE operations: bitwise equal
+
+
+def test_step_variates_reproduce_the_step():
+    """The recorded variates, injected into the deterministic step, give the same result."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    rng = np.random.default_rng(31)
+    n, H = 2000, pomdp.horizon
+    st = random_states(pomdp, n, rng)
+    b = _belief(pomdp, st)
+    sy = np.empty((n, H), np.int64); po = np.empty((n, H), np.int64); ga = np.empty((n, H)); fl = C.c_uint32()
+    check(b.ctx.lib.epi_step_variates(b.ctx.handle, b.handle, 0.3, SEED, 2, as_i64p(sy), as_i64p(po), as_f64p(ga), C.byref(fl)))
+    dev = b.download()
+    exp, _, _, _ = orc.step_injected(st, 0.3, sy, po, ga)
+    _eq(dev, exp)
+    exp2, _, _, _, _ = orc.step_batch(st, 0.3, seed=SEED, step=2)
+    _eq(dev, exp2)
+
+
+# ---------------------------------------------------------------------------
+# initial beliefs, mean, sample
+# ---------------------------------------------------------------------------
+def test_initial_beliefs_bit_exact():
+    pomdp = em.make_pomdp(LOD=5, test_delay=2)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    b = em.initialbelief(pomdp, 10_000, seed=5)
+    _eq(b.download(), orc.init_normal(10_000, 10_000.0, 5_000.0, 5))
+    b2 = em.random_states(pomdp, 10_000, seed=6)
+    _eq(b2.download(), orc.init_simplex(10_000, 6))
+
+
+def test_belief_mean_and_sample():
+    pomdp = em.make_pomdp(LOD=5, test_delay=2)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    rng = np.random.default_rng(41)
+    st = random_states(pomdp, 7777, rng)
+    b = _belief(pomdp, st)
+    m = em.mean(b)
+    eS, eI, eR, eT, bad = orc.mean(st)
+    assert (m.S, m.R) == (eS, eR) and (m.I == eI).all() and (m.Tests == eT.T).all() and not bad
+    s = em.rand(b, seed=1, ctr=2)
+    hits = np.flatnonzero((st[0] == s.S) & (st[2] == s.R) & (st[1] == s.I).all(axis=1))
+    assert hits.size >= 1
+
+
+# ---------------------------------------------------------------------------
+# the filter update
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 1000, 2048, 2049, 50_000])
+def test_pf_update_bit_exact(n):
+    pomdp = em.make_pomdp(LOD=5)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
+    a = 0.2
+    _, mu, _ = orc.log_weights(st, a, 0)
+    o = int(np.median(mu)) + 3
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED, step=4)
+    em.update(upd, b, em.Action(a), o)
+    exp, info = orc.pf_update(st, a, o, SEED, 4)
+    _eq(b.download(), exp)
+    assert upd.last_flags == info["flags"]
+    assert abs(upd.last_ess - info["ess"]) <= 1e-9 * info["ess"]
+    F = pyoracle.lib().orc_frac_bits(n)
+    ll = info["lwmax"] + np.log(info["W"] / 2.0 ** F / n) - 0.5 * np.log(2 * np.pi)
+    assert abs(upd.last_loglik - ll) <= 1e-9 * max(1.0, abs(ll))
+
+
+@pytest.mark.parametrize("delay", [0, 1, 5])
+def test_pf_closed_loop_bit_exact(delay):
+    """Several successive updates (the resampling gather is folded into the next
+    step on the device; the oracle materialises every posterior)."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n, a = 6000, 0.3
+    st = orc.init_normal(n, 8_000.0, 4_000.0, SEED + delay)
+    true = orc.init_normal(1, 8_000.0, 4_000.0, 777)
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    for day in range(6):
+        true, o, _, _, _ = orc.step_batch(true, a, seed=555, step=day)
+        em.update(upd, b, em.Action(a), int(o[0]))
+        st, info = orc.pf_update(st, a, int(o[0]), SEED, day)
+        assert upd.last_flags == info["flags"]
+        if day in (0, 3, 5):
+            _eq(b.download(), st)
+        m = em.mean(b)
+        eS, eI, eR, eT, bad = orc.mean(st)
+        assert (m.S, m.R) == (eS, eR) and (m.I == eI).all() and (m.Tests == eT.T).all()
+
+
+def test_pf_degenerate_weights():
+    pomdp = em.make_pomdp(LOD=5)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 3000
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 3)
+    # a = 0 and o = 5: every weight is zero -> particles kept, flag raised
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    em.update(upd, b, em.Action(0.0), 5)
+    exp, info = orc.pf_update(st, 0.0, 5, SEED, 0)
+    assert upd.last_flags & _lib.EPI_F_ZERO_W and info["flags"] & 8
+    _eq(b.download(), exp)
+    # a = 0 and o = 0: every weight is one -> uniform resampling
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    em.update(upd, b, em.Action(0.0), 0)
+    exp, info = orc.pf_update(st, 0.0, 0, SEED, 0)
+    _eq(b.download(), exp)
+    assert abs(upd.last_ess - n) < 1e-6
+    # an observation far in the tail: a single particle takes (almost) all the weight
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    em.update(upd, b, em.Action(0.5), 10 ** 6)
+    exp, info = orc.pf_update(st, 0.5, 10 ** 6, SEED, 0)
+    _eq(b.download(), exp)
+    assert upd.last_ess < 50
+
+
+def test_pf_sharded_phases_equal_single_update():
+    """Two shards in one process, exchanging through device buffers: the phased API
+    gives the same posterior as the one-call update for every slot."""
+    import torch
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    ctx = em.interface.context_for(pomdp)
+    lib = ctx.lib
+    n, G = 9001, 2
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 71)
+    # make the weights lopsided so that particles cross the shard boundary
+    st[1][: n // 2] //= 3
+    st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
+    starts = [(n * g) // G for g in range(G + 1)]
+    shards = []
+    for g in range(G):
+        m = starts[g + 1] - starts[g]
+        b = em.ParticleCollection(ctx, m, halo_cap=m)
+        b.upload(*(x[starts[g]:starts[g + 1]] for x in st))
+        check(lib.epi_belief_set_shard(b.handle, n, starts[g]))
+        shards.append(b)
+    a, seed = 0.25, 1234
+    _, mu, _ = orc.log_weights(st, a, 0)
+    o = int(np.quantile(mu, 0.9))
+    rows = lib.epi_state_rows(pomdp.horizon, pomdp.test_delay)
+    for step in range(3):
+        lm = []
+        for b in shards:
+            v = C.c_double()
+            check(lib.epi_pf_predict(ctx.handle, b.handle, a, o, seed, step, C.byref(v)))
+            lm.append(v.value)
+        gmax = max(lm)
+        w = (C.c_uint64 * G)()
+        for g, b in enumerate(shards):
+            wl, sq = C.c_uint64(), C.c_double()
+            check(lib.epi_pf_weigh(ctx.handle, b.handle, gmax, C.byref(wl), C.byref(sq)))
+            w[g] = wl.value
+        lo = (C.c_int64 * (G + 1))()
+        check(lib.epi_pf_plan(n, G, w, seed, step, lo))
+        for g, b in enumerate(shards):           # parents in shard g
+            for h, dst in enumerate(shards):     # slots owned by shard h
+                s0, s1 = max(lo[g], starts[h]), min(lo[g + 1], starts[h + 1])
+                if s1 <= s0:
+                    continue
+                if g == h:
+                    check(lib.epi_pf_select_local(ctx.handle, b.handle, G, g, w, seed, step, s0, s1))
+                else:
+                    buf = torch.empty(rows * (s1 - s0), dtype=torch.int32, device="cuda")
+                    check(lib.epi_pf_export(ctx.handle, b.handle, G, g, w, seed, step, s0, s1, C.c_void_p(buf.data_ptr())))
+                    torch.cuda.synchronize()
+                    check(lib.epi_pf_import(ctx.handle, dst.handle, s0, s1, C.c_void_p(buf.data_ptr())))
+        for b in shards:
+            fl = C.c_uint32()
+            check(lib.epi_pf_finish(ctx.handle, b.handle, C.byref(fl)))
+        st, info = orc.pf_update(st, a, o, seed, step)
+        got = [b.download() for b in shards]
+        _eq(tuple(np.concatenate([g_[k] for g_ in got]) for k in range(4)), st)
+
+
+# ---------------------------------------------------------------------------
+# rollouts
+# ---------------------------------------------------------------------------
+def test_rollout_bit_exact():
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n, T = 800, 12
+    st = orc.init_simplex(n, 9)
+    rng = np.random.default_rng(9)
+    for actions in (0.4, rng.random(T), rng.random(n), rng.random((n, T))):
+        b = _belief(pomdp, st)
+        hist, rew, fl = em.rollout_batch(b, T, actions, seed=77, step0=5)
+        exp, ehist, erew, efl = orc.rollout(st, T, actions, seed=77, step0=5)
+        _eq(b.download(), exp)
+        assert (hist == ehist).all() and fl == efl
+        assert (rew.view(np.uint64) == erew.view(np.uint64)).all()
+
+
+def test_reference_bounds_property_on_device():
+    """test/InfectionSimTest.jl:14-30 through Simulate(): 0 <= S, sum(I), R <= N for
+    7 parameter sets x 6 actions, T = 100."""
+    for pidx, pomdp in enumerate(reference_test_params()):
+        rng = np.random.default_rng(pidx)
+        for a in np.arange(0, 1.01, 0.2):
+            h = em.Simulate(100, em.State_random(pomdp, rng), pomdp, em.Action(float(a)), seed=pidx)
+            arr = h.Array()
+            assert arr.shape == (3, 100) and (arr >= 0).all() and (arr <= pomdp.N).all()
+            assert (arr.sum(axis=0) == pomdp.N).all()
+
+
+def test_gen_and_ensemble():
+    pomdp = em.make_pomdp(LOD=5, test_period=3)
+    orc = pyoracle.Oracle(em.unity_test_period(pomdp).to_c())
+    s = em.State_from([2000] * 14, pomdp)
+    sp, o, r = em.gen(pomdp, s, em.Action(0.3), seed=8, step=2)
+    st = (np.array([s.S]), s.I[None, :], np.array([s.R]), s.Tests.T[None])
+    rs, prev = 0.0, 0.0
+    for i in range(3):
+        st, eo, er, _, _ = orc.step_batch(st, 0.3, prev, seed=8, step=6 + i)
+        rs, prev = rs + er[0], 0.3
+    assert sp.S == st[0][0] and (sp.I == st[1][0]).all() and sp.R == st[2][0] and o == eo[0] and r == rs
+    ens = em.SimulateEnsemble(30, 500, pomdp, em.Action(0.2), seed=3)
+    assert ens.shape == (3, 30, 500) and (ens.sum(axis=0) == pomdp.N).all() and (ens >= 0).all()
+
+
+# ---------------------------------------------------------------------------
+# full-size properties (no oracle at these sizes)
+# ---------------------------------------------------------------------------
+def test_large_belief_properties():
+    pomdp = em.make_pomdp(LOD=5)
+    n = 2_000_000
+    b = em.initialbelief(pomdp, n, seed=SEED)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    for day in range(3):
+        em.update(upd, b, em.Action(0.2), 9000 - 200 * day)
+        assert upd.last_flags == 0 and 1 < upd.last_ess <= n
+    S, I, R, T = b.download()
+    assert (S + I.sum(axis=1) + R == pomdp.N).all()          # population conserved through predict + resample
+    assert (I >= 0).all() and (R >= 0).all() and (S >= 0).all()
+    # same seeds -> same posterior (counter-based streams)
+    b2 = em.initialbelief(pomdp, n, seed=SEED)
+    upd2 = em.BootstrapFilter(pomdp, n, seed=SEED)
+    for day in range(3):
+        em.update(upd2, b2, em.Action(0.2), 9000 - 200 * day)
+    S2, I2, R2, T2 = b2.download()
+    assert (S == S2).all() and (I == I2).all() and (R == R2).all()
+    m = em.mean(b)
+    assert m.S == int(np.rint(S.sum() / n)) and (m.I == np.rint(I.sum(axis=0) / n)).all()
