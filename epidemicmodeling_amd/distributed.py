@@ -1,0 +1,230 @@
+"""Particle filter sharded by particle index over the GPUs of one node: one
+process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI) for the
+exchange steps of an update.
+
+Global slot m lives on rank g iff start[g] <= m < start[g+1], start[g] =
+floor(n_total * g / G).  Random streams and resampling positions are addressed
+by the GLOBAL slot, and weights are summed in fixed point, so the posterior is
+bit-identical for every G.
+
+Per update (reference: update(BootstrapFilter, b, a, o), call sites
+src/POMDPsInterface.jl:56, src/MPC.jl:393):
+  1. local fused weight + step                          (no communication)
+  2. all-reduce MAX of the local maximum log weight     (1 double)
+  3. local fixed-point weights + prefix sums
+  4. all-gather of the local weight totals and sums of squares (2 values/rank)
+  5. every rank derives the same plan: shard g's particles are the ancestors of
+     global slots [lo[g], lo[g+1])
+  6. slots of that range owned by another rank: the resampled particles are
+     packed and sent directly to the owner (pairwise send/recv, no ring);
+     slots owned locally only get an ancestor index (the gather is folded into
+     the next step kernel).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_i64p, check
+from .params import CovidPOMDP
+
+
+def shard_starts(n_total: int, world: int) -> List[int]:
+    return [(n_total * g) // world for g in range(world + 1)]
+
+
+class LibShard:
+    """The local shard, held by libepi_gfx950.so on one device."""
+
+    def __init__(self, pomdp: CovidPOMDP, n_local: int, n_total: int, slot0: int, device: int):
+        from .interface import ParticleCollection, context_for
+        import torch
+        self.torch = torch
+        self.ctx = context_for(pomdp, device)
+        self.lib = self.ctx.lib
+        self.b = ParticleCollection(self.ctx, n_local, halo_cap=n_local if n_total > n_local else 0)
+        check(self.lib.epi_belief_set_shard(self.b.handle, n_total, slot0))
+        self.rows = self.lib.epi_state_rows(pomdp.horizon, pomdp.test_delay)
+        self.comm_device = torch.device("cuda", device)
+
+    def init_normal(self, mu, sigma, seed):
+        check(self.lib.epi_belief_init_normal(self.b.handle, mu, sigma, seed))
+
+    def upload(self, S, I, R, T=None):
+        self.b.upload(S, I, R, T)
+
+    def download(self):
+        return self.b.download()
+
+    def predict(self, a, o, seed, step) -> float:
+        v = C.c_double()
+        check(self.lib.epi_pf_predict(self.ctx.handle, self.b.handle, a, int(o), seed, step, C.byref(v)))
+        return v.value
+
+    def weigh(self, lwmax):
+        w, sq = C.c_uint64(), C.c_double()
+        check(self.lib.epi_pf_weigh(self.ctx.handle, self.b.handle, lwmax, C.byref(w), C.byref(sq)))
+        return w.value, sq.value
+
+    def plan(self, n_total, w_shard, seed, step):
+        G = len(w_shard)
+        w = (C.c_uint64 * G)(*w_shard)
+        lo = (C.c_int64 * (G + 1))()
+        check(self.lib.epi_pf_plan(n_total, G, w, seed, step, lo))
+        return list(lo)
+
+    def select_local(self, g, w_shard, seed, step, s0, s1):
+        G = len(w_shard)
+        w = (C.c_uint64 * G)(*w_shard)
+        check(self.lib.epi_pf_select_local(self.ctx.handle, self.b.handle, G, g, w, seed, step, s0, s1))
+
+    def export(self, g, w_shard, seed, step, s0, s1):
+        G = len(w_shard)
+        w = (C.c_uint64 * G)(*w_shard)
+        buf = self.torch.empty(self.rows * (s1 - s0), dtype=self.torch.int32, device=self.comm_device)
+        check(self.lib.epi_pf_export(self.ctx.handle, self.b.handle, G, g, w, seed, step, s0, s1, C.c_void_p(buf.data_ptr())))
+        return buf
+
+    def recv_buffer(self, count):
+        return self.torch.empty(self.rows * count, dtype=self.torch.int32, device=self.comm_device)
+
+    def import_(self, s0, s1, buf):
+        self.torch.cuda.current_stream().synchronize()
+        check(self.lib.epi_pf_import(self.ctx.handle, self.b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
+
+    def finish(self) -> int:
+        fl = C.c_uint32()
+        check(self.lib.epi_pf_finish(self.ctx.handle, self.b.handle, C.byref(fl)))
+        return fl.value
+
+    def sums(self) -> np.ndarray:
+        p = self.ctx.pomdp
+        out = np.zeros(2 + p.horizon + (p.test_delay + 1) * p.horizon, dtype=np.int64)
+        check(self.lib.epi_belief_sums(self.ctx.handle, self.b.handle, as_i64p(out)))
+        return out
+
+    def timing(self, on: bool):
+        check(self.lib.epi_ctx_timing(self.ctx.handle, int(on)))
+
+    def timing_read(self):
+        s, c = C.c_double(), C.c_int64()
+        check(self.lib.epi_ctx_timing_read(self.ctx.handle, C.byref(s), C.byref(c)))
+        return s.value, c.value
+
+
+class ShardedFilter:
+    """BootstrapFilter over a population sharded across the ranks of the default
+    process group.  `shard` may be supplied (tests use a CPU stand-in with the
+    LibShard interface); by default it is the device library."""
+
+    def __init__(self, pomdp: CovidPOMDP, n_total: int, seed: int = 0x5EED, device: int = 0, shard=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.pomdp, self.n_total, self.seed = pomdp, int(n_total), seed
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.starts = shard_starts(self.n_total, self.world)
+        self.slot0, self.n_local = self.starts[self.rank], self.starts[self.rank + 1] - self.starts[self.rank]
+        if self.n_local < 1:
+            raise ValueError("fewer particles than ranks")
+        self.shard = shard if shard is not None else LibShard(pomdp, self.n_local, self.n_total, self.slot0, device)
+        self.comm_device = self.shard.comm_device
+        self.step = 0
+        self.frac_bits = _frac_bits(self.n_total)
+
+    # -- population ---------------------------------------------------------
+    def init_normal(self, mu: float, sigma: float):
+        self.shard.init_normal(mu, sigma, self.seed)
+
+    def upload_local(self, S, I, R, T=None):
+        self.shard.upload(S, I, R, T)
+
+    def download_local(self):
+        return self.shard.download()
+
+    def timing(self, on: bool):
+        self.shard.timing(on)
+
+    def timing_read(self):
+        return self.shard.timing_read()
+
+    # -- update -------------------------------------------------------------
+    def update(self, a: float, o: int) -> dict:
+        torch, dist = self.torch, self.dist
+        G, g, seed, step = self.world, self.rank, self.seed, self.step
+        sh = self.shard
+        # 1-2: fused weight + step, global maximum log weight
+        t = torch.tensor([sh.predict(a, o, seed, step)], dtype=torch.float64, device=self.comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lwmax = float(t[0])
+        # 3-4: local fixed-point weights, totals of every shard
+        w_local, sq_local = sh.weigh(lwmax)
+        mine = torch.tensor([float(w_local), sq_local], dtype=torch.float64, device=self.comm_device)   # totals are < 2^53: exact
+        allv = [torch.empty_like(mine) for _ in range(G)]
+        dist.all_gather(allv, mine)
+        w_shard = [int(v[0]) for v in allv]
+        sumsq = math.fsum(float(v[1]) for v in allv)
+        # 5: the plan (identical on every rank)
+        lo = sh.plan(self.n_total, w_shard, seed, step)
+        st = self.starts
+        # 6: exchange the particles whose slot is owned by another rank
+        ops, recvs = [], []
+        for h in range(G):
+            if h == g:
+                continue
+            s0, s1 = max(lo[g], st[h]), min(lo[g + 1], st[h + 1])          # my particles -> slots of rank h
+            if s1 > s0:
+                ops.append(dist.P2POp(dist.isend, sh.export(g, w_shard, seed, step, s0, s1), h))
+            r0, r1 = max(lo[h], st[g]), min(lo[h + 1], st[g + 1])          # rank h's particles -> my slots
+            if r1 > r0:
+                buf = sh.recv_buffer(r1 - r0)
+                recvs.append((r0, r1, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, h))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for r0, r1, buf in recvs:
+            sh.import_(r0, r1, buf)
+        s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
+        if s1 > s0:
+            sh.select_local(g, w_shard, seed, step, s0, s1)
+        flags = sh.finish()
+        # OR of the per-rank flag words as a MAX over their bits (RCCL has no bitwise reductions)
+        ft = torch.tensor([(flags >> k) & 1 for k in range(8)], dtype=torch.int64, device=self.comm_device)
+        dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        W = sum(w_shard)
+        flags = sum(int(ft[k]) << k for k in range(8)) | (_lib.EPI_F_ZERO_W if W == 0 else 0)
+        self.step += 1
+        loglik = (lwmax + math.log(W / 2.0 ** self.frac_bits / self.n_total) - 0.5 * math.log(2 * math.pi)) if W else float("-inf")
+        return {"loglik": loglik, "ess": (float(W) ** 2 / sumsq) if sumsq > 0 else 0.0, "flags": flags,
+                "moved": sum(r1 - r0 for r0, r1, _ in recvs), "w_shard": w_shard, "lo": lo}
+
+    # -- summaries ----------------------------------------------------------
+    def mean(self):
+        """mean(pc, pomdp) (src/updater.jl:5-25) of the whole sharded population:
+        integer sums added over ranks, then rounded once."""
+        torch, dist = self.torch, self.dist
+        sums = torch.from_numpy(self.shard.sums()).to(self.comm_device)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        sums = sums.cpu().numpy()
+        p = self.pomdp
+        H, D1 = p.horizon, p.test_delay + 1
+        n = self.n_total
+        avgS = int(np.rint(np.float64(int(sums[0])) / n))
+        avgI = np.rint(sums[2:2 + H].astype(np.float64) / n).astype(np.int64)
+        avgR = p.N - (avgS + int(avgI.sum()))
+        avgT = np.rint(sums[2 + H:].astype(np.float64) / n).astype(np.int64).reshape(H, D1).T
+        if avgR < 0:
+            raise ValueError("mean R < 0 (src/updater.jl:18 asserts)")
+        return avgS, avgI, avgR, avgT
+
+
+def _frac_bits(n_total: int) -> int:
+    lg = 0
+    while (1 << lg) < n_total:
+        lg += 1
+    return min(40, 53 - lg)

@@ -1,0 +1,102 @@
+"""The sharded update's host logic under gloo, world_size 2, on CPU: collectives,
+resampling plan and pairwise particle exchange, with the oracle standing in for
+the device shard.  The sharded posterior must equal the single-process oracle
+update slot for slot."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import epidemicmodeling_amd as em
+from epidemicmodeling_amd import _lib
+from epidemicmodeling_amd.distributed import ShardedFilter, shard_starts
+from oracle import pyoracle
+from oracle_shard import OracleShard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _prior(pomdp, n, lopsided):
+    orc = pyoracle.Oracle(pomdp.to_c())
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 71)
+    if lopsided:                      # far fewer infected in the first half: its weights collapse, particles cross shards
+        st[1][: n // 2] //= 3
+        st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
+    return orc, st
+
+
+def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+        _, st = _prior(pomdp, n, lopsided)
+        starts = shard_starts(n, world)
+        sl = slice(starts[rank], starts[rank + 1])
+        f = ShardedFilter(pomdp, n, seed=1234, shard=OracleShard(pomdp, starts[rank + 1] - starts[rank], n, starts[rank]))
+        f.upload_local(*(x[sl] for x in st))
+        infos = []
+        for o in obs:
+            infos.append(f.update(a, o))
+        S, I, R, T = f.download_local()
+        mS, mI, mR, mT = f.mean()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), S=S, I=I, R=R, T=T, mS=mS, mI=mI, mR=mR, mT=mT,
+                 ess=[i["ess"] for i in infos], ll=[i["loglik"] for i in infos], moved=[i["moved"] for i in infos],
+                 flags=[i["flags"] for i in infos])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("delay,lopsided,world", [(0, False, 2), (1, True, 2), (0, True, 3)])
+def test_sharded_update_equals_single_process(tmp_path, delay, lopsided, world):
+    n, a = 3001, 0.25
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc, st = _prior(pomdp, n, lopsided)
+    _, mu, _ = orc.log_weights(st, a, 0)
+    obs = [int(np.quantile(mu, q)) for q in (0.9, 0.5, 0.7)]
+    mp.spawn(_worker, args=(world, _free_port(), n, delay, lopsided, a, obs, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    exp, infos = st, []
+    for step, o in enumerate(obs):
+        exp, info = orc.pf_update(exp, a, o, 1234, step)
+        infos.append(info)
+    for k, name in enumerate("SIRT"):
+        got = np.concatenate([p[name] for p in parts])
+        assert (got == exp[k]).all(), name
+    eS, eI, eR, eT, _ = orc.mean(exp)
+    for p in parts:
+        assert int(p["mS"]) == eS and int(p["mR"]) == eR and (p["mI"] == eI).all() and (p["mT"] == eT.T).all()
+        assert np.allclose(p["ess"], [i["ess"] for i in infos], rtol=1e-9)
+        assert (p["flags"] == [i["flags"] for i in infos]).all()
+    if lopsided:
+        assert sum(int(p["moved"].sum()) for p in parts) > 0          # particles did cross the shard boundary
+
+
+def test_plan_matches_standin_and_covers_all_slots():
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    pomdp = em.make_pomdp(LOD=5)
+    for trial in range(200):
+        G = int(rng.integers(1, 9))
+        n = int(rng.integers(G, 5000))
+        w = [int(x) for x in rng.integers(0, 2 ** 40, G)]
+        if trial % 5 == 0:
+            w[int(rng.integers(0, G))] = 0
+        if trial % 17 == 0:
+            w = [0] * G
+        sh = OracleShard(pomdp, 1, n, 0)
+        ref = sh.plan(n, w, 99, trial)
+        arr = (C.c_uint64 * G)(*w)
+        lo = (C.c_int64 * (G + 1))()
+        assert lib.epi_pf_plan(n, G, arr, 99, trial, lo) == 0
+        assert list(lo) == ref
+        assert lo[0] == 0 and lo[G] == n and all(lo[i] <= lo[i + 1] for i in range(G))
