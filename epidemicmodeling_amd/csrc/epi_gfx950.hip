@@ -35,6 +35,7 @@ using namespace epi;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
+static int g_screen = 1;     // see epi_debug_screen
 
 static int fail(int code, const char* fmt, ...)
 {
@@ -161,6 +162,7 @@ struct StepArgs {
     int32_t* pos_out;
     // recorded variates (MODE_RECORD)
     int32_t* rec_sympt; int32_t* rec_pos; double* rec_gam;
+    int screen;                 // 1: the rejection samplers may use their binary32 screens
 };
 
 enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const epi_params
             RecordingDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else {
-            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step)};
+            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         }
         flags = res.flags;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(TPB) void k_sums(int64_t n, const int32_t* __restri
 // bare samplers (element j draws from the streams of slot j)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_sample_binomial(int64_t count, const int32_t* __restrict__ n, const double* __restrict__ p,
-                                                          uint64_t seed, uint32_t step, uint32_t bin, int which, int32_t* __restrict__ out)
+                                                          uint64_t seed, uint32_t step, uint32_t bin, int which, int32_t* __restrict__ out, bool screen)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= count) return;
@@ -451,12 +453,12 @@ __global__ __launch_bounds__(TPB) void k_sample_binomial(int64_t count, const in
 }
 
 __global__ __launch_bounds__(TPB) void k_sample_gamma(int64_t count, const double* __restrict__ shape, const double* __restrict__ scale,
-                                                       uint64_t seed, uint32_t step, uint32_t bin, double* __restrict__ out)
+                                                       uint64_t seed, uint32_t step, uint32_t bin, double* __restrict__ out, bool screen)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= count) return;
     Rng g = rng_make(seed, (uint64_t)j, step);
-    out[j] = gamma_draw(shape[j], scale[j], g, bin);
+    out[j] = gamma_draw(shape[j], scale[j], g, bin, screen);
 }
 
 // ---------------------------------------------------------------------------
@@ -821,6 +823,7 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
     DevBuf da, dap, dob, dr, dni;
     StepArgs A;
     memset(&A, 0, sizeof A);
+    A.screen = g_screen;
     A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
@@ -885,6 +888,7 @@ int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_part
     HIPCHECK(hipMemcpyAsync(dg.p, hg.data(), 8 * cnt, hipMemcpyHostToDevice, c->stream));
     StepArgs A;
     memset(&A, 0, sizeof A);
+    A.screen = g_screen;
     A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
@@ -933,6 +937,7 @@ int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32
         return fail(EPI_ENOMEM, "epi_step_variates: hipMalloc failed");
     StepArgs A;
     memset(&A, 0, sizeof A);
+    A.screen = g_screen;
     A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a; A.a_row_stride = 1;
@@ -974,7 +979,7 @@ int epi_sample_binomial(epi_ctx* c, int64_t count, const int64_t* n, const doubl
         return fail(EPI_ENOMEM, "epi_sample_binomial: hipMalloc failed");
     HIPCHECK(hipMemcpyAsync(dn.p, hn.data(), 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(dp.p, p, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>());
+    k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>(), g_screen != 0);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(hn.data(), dout.p, 4 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -992,7 +997,7 @@ int epi_sample_gamma(epi_ctx* c, int64_t count, const double* shape, const doubl
         return fail(EPI_ENOMEM, "epi_sample_gamma: hipMalloc failed");
     HIPCHECK(hipMemcpyAsync(dk.p, shape, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(ds.p, scale, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>());
+    k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>(), g_screen != 0);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(out, dout.p, 8 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -1018,6 +1023,7 @@ int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, i
     for (int t = 0; t < T; t++) {
         StepArgs A;
         memset(&A, 0, sizeof A);
+    A.screen = g_screen;
         A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
         A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
         const int64_t tcol = act_per_day ? t : 0;
@@ -1071,6 +1077,7 @@ static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
     k_scal_reset<<<1, 1, 0, c->stream>>>(c->d_scal);
     StepArgs A;
     memset(&A, 0, sizeof A);
+    A.screen = g_screen;
     A.n = b->n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a; A.a_row_stride = 1;
@@ -1146,6 +1153,12 @@ int epi_pf_update(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed,
     int rc = epi_pf_update_async(c, b, a, o, seed, step);
     if (rc) return rc;
     return epi_pf_collect(c, b, loglik, ess, flags);
+}
+
+int epi_debug_screen(int enable)
+{
+    g_screen = enable != 0;
+    return EPI_OK;
 }
 
 int epi_ctx_timing(epi_ctx* c, int enable)

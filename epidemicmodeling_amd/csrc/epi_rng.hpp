@@ -191,16 +191,74 @@ EPI_HD double stirling_tail(double k)
         t = (i == 9) ? 0.008330563433362871 : t;
         return t;
     }
-    double kp1 = k + 1.0;
-    double kp1sq = kp1 * kp1;
-    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / kp1;
+    double r = 1.0 / (k + 1.0);
+    double r2 = r * r;
+    return (0.08333333333333333 - (0.002777777777777778 - 0.0007936507936507937 * r2) * r2) * r;
 }
 
 constexpr uint32_t BINOM_MAX_ATTEMPTS = 512u;
 
+// ---- single-precision screens (device only) ---------------------------------------
+// The accept/reject decisions of the two rejection samplers are DEFINED by the
+// binary64 expressions in binomial_draw / gamma_draw below.  On the device most
+// of those evaluations are avoided: the same quantity is first estimated in
+// binary32 with the hardware reciprocal / log2 approximations, in a form without
+// cancellation, and the estimate decides whenever it is further from the
+// threshold than a guard band many times its error bound.  Only draws inside the
+// band fall through to the defining binary64 expression, so results are
+// unchanged bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPI_HAVE_SCREEN 1
+__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float f_ln(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
+
+// log1p(t) - t for t > -1: series below 1/8, hardware log above
+__device__ __forceinline__ float f_log1p_minus(float t)
+{
+    float p = 0.111111111f;
+    p = __builtin_fmaf(p, t, -0.125f);
+    p = __builtin_fmaf(p, t, 0.142857143f);
+    p = __builtin_fmaf(p, t, -0.166666667f);
+    p = __builtin_fmaf(p, t, 0.2f);
+    p = __builtin_fmaf(p, t, -0.25f);
+    p = __builtin_fmaf(p, t, 0.333333333f);
+    p = __builtin_fmaf(p, t, -0.5f);
+    float ser = (t * t) * p;
+    float big = f_ln(1.0f + t) - t;
+    return __builtin_fabsf(t) <= 0.125f ? ser : big;
+}
+
+// Stirling tail for k >= 2 (argument k + 1 >= 3), error < 3e-7
+__device__ __forceinline__ float f_stirling_tail(float kp1)
+{
+    float r = f_rcp(kp1), r2 = r * r;
+    return r * __builtin_fmaf(r2, __builtin_fmaf(r2, 7.93650794e-4f, -2.77777778e-3f), 8.33333333e-2f);
+}
+#endif
+
+// The defining acceptance test of the transformed-rejection sampler (Hoermann 1993, step 3):
+// log(v alpha / (a/us^2 + b)) <= log f(k) - log f(m), with Stirling-corrected log factorials.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline))
+#else
+static inline
+#endif
+bool btrs_accept_exact(double nd, double pp, double qq, double m, double kd, double v, double us, double a, double b, double alpha)
+{
+    const double r = pp / qq;
+    const double lv = s_log(v * alpha / (a / (us * us) + b));
+    const double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
+                    + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
+                    + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
+                    + stirling_tail(m) + stirling_tail(nd - m)
+                    - stirling_tail(kd) - stirling_tail(nd - kd);
+    return lv <= ub;
+}
+
 // fa, fb: the attempt-0 word pair; attempts a >= 1 come from blocks of retry_kind.
+// screen: allow the binary32 screen (device only; never changes the result).
 EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
-                             const Rng& g, uint32_t retry_kind, uint32_t bin)
+                             const Rng& g, uint32_t retry_kind, uint32_t bin, bool screen = true)
 {
     if (n <= 0 || !(p > 0.0)) return 0;
     if (p >= 1.0) return n;
@@ -221,38 +279,80 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
             r *= (a / (double)x - s);
         }
     } else {
-        double spq = __builtin_sqrt(nd * pp * qq);
-        double b = 1.15 + 2.53 * spq;
-        double a = -0.0873 + 0.0248 * b + 0.01 * pp;
-        double c = nd * pp + 0.5;
-        double vr = 0.92 - 4.2 / b;
-        double alpha = (2.83 + 5.1 / b) * spq;
-        double r = pp / qq;
-        double m = __builtin_floor((nd + 1.0) * pp);
+        // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
+        const double spq = (double)__builtin_sqrtf((float)(nd * pp * qq));
+        const double b = 1.15 + 2.53 * spq;
+        const double a = -0.0873 + 0.0248 * b + 0.01 * pp;
+        const double c = nd * pp + 0.5;
+        const double ib = (double)(1.0f / (float)b);
+        const double vr = 0.92 - 4.2 * ib;
+        const double alpha = (2.83 + 5.1 * ib) * spq;
+        const double mt = (nd + 1.0) * pp;
+        const double m = __builtin_floor(mt);
         x = (int32_t)m;
-        uint32_t w[4] = {fa, fb, 0u, 0u};
-        for (uint32_t att = 0; att < BINOM_MAX_ATTEMPTS; att++) {
-            uint32_t wa, wb;
-            if (att == 0) { wa = fa; wb = fb; }
-            else {
-                uint32_t half = (att - 1u) & 1u;
-                if (half == 0u) rng_block(g, retry_kind, bin, (att - 1u) >> 1, w);
-                wa = half ? w[2] : w[0];
-                wb = half ? w[3] : w[1];
+#ifdef EPI_HAVE_SCREEN
+        // per-draw constants of the screens.  With m1 = m+1, n1 = n-m+1, dk = k-m:
+        //   ub = -dk LA - dk(dk+1/2)/n1 - dk(dk-1/2)/m1 - (n-k+1/2) g(-dk/n1) - (k+1/2) g(dk/m1)
+        //        + fc(m) + fc(n-m) - fc(k) - fc(n-k),      g(t) = log1p(t) - t,
+        //   LA = log((m+1) q / (p n1)) = log1p((1 - frac((n+1)p) - p) / (p n1))
+        // which is the defining expression (btrs_accept_exact) rearranged so that no large terms cancel.
+        const bool scr = screen && nd < 16777216.0;
+        const float m1f = (float)(m + 1.0), n1f = (float)(nd - m + 1.0);
+        const float rm1 = f_rcp(m1f), rn1 = f_rcp(n1f);
+        const float dA = (float)(1.0 - (mt - m) - pp) * f_rcp((float)pp * n1f);
+        const float LA = dA + f_log1p_minus(dA);
+        const float fcm = f_stirling_tail(m1f) + f_stirling_tail(n1f);
+        const float af = (float)a, bf = (float)b, alf = (float)alpha;
+        const double cfl = __builtin_floor(c);
+        const float cfr = (float)(c - cfl);
+#endif
+        uint32_t w[4] = {0u, 0u, fa, fb};
+        // attempt j-1 takes words (2,3) of its block when j is odd and words (0,1) when j is even;
+        // the attempt-0 pair sits in words (2,3) of the initial contents
+#pragma unroll 1
+        for (uint32_t j = 1; j <= BINOM_MAX_ATTEMPTS; j++) {
+            const uint32_t half = j & 1u;
+            if (half == 0u) rng_block(g, retry_kind, bin, (j - 2u) >> 1, w);
+            const uint32_t wa = half ? w[2] : w[0];
+            const uint32_t wb = half ? w[3] : w[1];
+            const double u = u01(wa) - 0.5;
+            const double v = u01(wb);
+            const double us = 0.5 - __builtin_fabs(u);
+            double kd;
+            bool have_k = false;
+#ifdef EPI_HAVE_SCREEN
+            if (scr) {
+                // k = floor((2a/us + b) u + c) estimated in binary32; trusted when the value is
+                // further from an integer than many times its error bound
+                const float t = __builtin_fmaf(__builtin_fmaf(2.0f * af, f_rcp((float)us), bf), (float)u, cfr);
+                const float tf = __builtin_floorf(t);
+                const float fr = t - tf;
+                const float dl = __builtin_fmaf(__builtin_fabsf(t) + bf, 4e-6f, 1e-3f);
+                if (fr > dl && fr < 1.0f - dl) { kd = cfl + (double)tf; have_k = true; }
             }
-            double u = u01(wa) - 0.5;
-            double v = u01(wb);
-            double us = 0.5 - __builtin_fabs(u);
-            double kd = __builtin_floor((2.0 * a / us + b) * u + c);
+#endif
+            if (!have_k) kd = __builtin_floor((2.0 * a / us + b) * u + c);
             if (kd < 0.0 || kd > nd) continue;
             if (us >= 0.07 && v <= vr) { x = (int32_t)kd; break; }
-            double lv = s_log(v * alpha / (a / (us * us) + b));
-            double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
-                      + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
-                      + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
-                      + stirling_tail(m) + stirling_tail(nd - m)
-                      - stirling_tail(kd) - stirling_tail(nd - kd);
-            if (lv <= ub) { x = (int32_t)kd; break; }
+#ifdef EPI_HAVE_SCREEN
+            if (scr && kd >= 2.0 && nd - kd >= 2.0) {
+                const float dk = (float)(kd - m);
+                const float k1f = m1f + dk, nk1f = n1f - dk;
+                const float usf = (float)us;
+                const float lv = f_ln((float)v * alf * f_rcp(__builtin_fmaf(af, f_rcp(usf * usf), bf)));
+                const float t_a = dk * LA;
+                const float t_l1 = dk * (dk + 0.5f) * rn1, t_l2 = dk * (dk - 0.5f) * rm1;
+                const float t_g1 = (nk1f - 0.5f) * f_log1p_minus(-dk * rn1), t_g2 = (k1f - 0.5f) * f_log1p_minus(dk * rm1);
+                const float t_fc = f_stirling_tail(k1f) + f_stirling_tail(nk1f);
+                const float ub = fcm - t_fc - t_a - t_l1 - t_l2 - t_g1 - t_g2;
+                const float mag = __builtin_fabsf(lv) + __builtin_fabsf(t_a) + t_l1 + t_l2 - t_g1 - t_g2 + fcm + t_fc;
+                const float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
+                const float diff = lv - ub;
+                if (diff < -guard) { x = (int32_t)kd; break; }
+                if (diff > guard) continue;
+            }
+#endif
+            if (btrs_accept_exact(nd, pp, qq, m, kd, v, us, a, b, alpha)) { x = (int32_t)kd; break; }
         }
     }
     return flip ? n - x : x;
@@ -262,7 +362,7 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
 // Marsaglia-Tsang (2000); shape < 1 boosted by U^(1/shape); shape < 2^-30 -> 0.
 constexpr uint32_t GAMMA_MAX_ATTEMPTS = 512u;
 
-EPI_HD double gamma_draw(double shape, double scale, const Rng& g, uint32_t bin)
+EPI_HD double gamma_draw(double shape, double scale, const Rng& g, uint32_t bin, bool screen = true)
 {
     if (!(shape >= 0x1p-30)) return 0.0;
     const bool boost = shape < 1.0;
@@ -272,18 +372,50 @@ EPI_HD double gamma_draw(double shape, double scale, const Rng& g, uint32_t bin)
     double v = 1.0;
     uint32_t w[4] = {0u, 0u, 0u, 0u};
     float z0 = 0.f, z1 = 0.f;
+#ifdef EPI_HAVE_SCREEN
+    const float cf = (float)c, df = (float)d;
+#endif
     for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
         if ((att & 1u) == 0u) {
             rng_block(g, K_GAMMA, bin, att >> 1, w);
             box_muller(w[0], w[1], z0, z1);
         }
-        double x = (double)((att & 1u) ? z1 : z0);
+        const float xf = (att & 1u) ? z1 : z0;
+        double x = (double)xf;
         double u = u01((att & 1u) ? w[3] : w[2]);
         double t = 1.0 + c * x;
         if (!(t > 0.0)) continue;
         double vv = t * t * t;
         double x2 = x * x;
         if (u < 1.0 - 0.0331 * (x2 * x2)) { v = vv; break; }
+#ifdef EPI_HAVE_SCREEN
+        if (screen) {
+            // x^2/2 + d (1 - v + log v) = 3 d (log1p(t) - t + t^2/2 - t^3/3), t = c x  (since 9 d c^2 = 1)
+            float tf = cf * xf;
+            if (tf > -0.9f) {
+                float t2 = tf * tf;
+                float q = 0.1f;
+                q = __builtin_fmaf(q, tf, -0.111111111f);
+                q = __builtin_fmaf(q, tf, 0.125f);
+                q = __builtin_fmaf(q, tf, -0.142857143f);
+                q = __builtin_fmaf(q, tf, 0.166666667f);
+                q = __builtin_fmaf(q, tf, -0.2f);
+                q = __builtin_fmaf(q, tf, 0.25f);
+                float ser = -(t2 * t2) * q;                                   // log1p(t) - t + t^2/2 - t^3/3
+                float l1p = f_ln(1.0f + tf);
+                float big = l1p - tf + 0.5f * t2 - 0.333333333f * t2 * tf;
+                float magb = __builtin_fabsf(l1p) + __builtin_fabsf(tf) + 0.5f * t2 + 0.333333333f * __builtin_fabsf(t2 * tf);
+                bool small = __builtin_fabsf(tf) <= 0.125f;
+                float rhs = 3.0f * df * (small ? ser : big);
+                float lu = f_ln((float)u);
+                float mag = __builtin_fabsf(lu) + 3.0f * df * (small ? __builtin_fabsf(ser) : magb);
+                float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
+                float diff = lu - rhs;
+                if (diff < -guard) { v = vv; break; }
+                if (diff > guard) continue;
+            }
+        }
+#endif
         if (s_log(u) < 0.5 * x2 + d * (1.0 - vv + s_log(vv))) { v = vv; break; }
     }
     double gval = d * v;

@@ -37,17 +37,23 @@ __host__ __device__ __forceinline__ int tests_row(int H, int r0, int c0) { retur
 // Variates from the Philox streams of one (slot, step).
 struct PhiloxDraws {
     Rng g;
+    bool screen;    // allow the binary32 screens of the rejection samplers (results do not depend on it)
     __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double q, int32_t n_tested, double p,
                                                int32_t& sympt, int32_t& pos) const
     {
         uint32_t w[4];
         rng_block(g, K_BINOM0, (uint32_t)bin, 0, w);
-        sympt = binomial_draw(n_inf, q, w[0], w[1], g, K_SYMPT, (uint32_t)bin);
-        pos = binomial_draw(n_tested, p, w[2], w[3], g, K_POS, (uint32_t)bin);
+        // one instance of the sampler code for both draws
+#pragma unroll 1
+        for (int j = 0; j < 2; j++) {
+            const int32_t r = binomial_draw(j ? n_tested : n_inf, j ? p : q, j ? w[2] : w[0], j ? w[3] : w[1],
+                                            g, j ? K_POS : K_SYMPT, (uint32_t)bin, screen);
+            if (j) pos = r; else sympt = r;
+        }
     }
     __device__ __forceinline__ double gamma(int bin, double shape, double scale) const
     {
-        return gamma_draw(shape, scale, g, (uint32_t)bin);
+        return gamma_draw(shape, scale, g, (uint32_t)bin, screen);
     }
 };
 
@@ -58,7 +64,7 @@ struct RecordingDraws {
     __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double q, int32_t n_tested, double p,
                                                int32_t& s, int32_t& ps) const
     {
-        PhiloxDraws d{g};
+        PhiloxDraws d{g, true};
         d.binomials(bin, n_inf, q, n_tested, p, s, ps);
         sympt[(int64_t)bin * n + idx] = s;
         pos[(int64_t)bin * n + idx] = ps;
@@ -149,20 +155,27 @@ __device__ __forceinline__ StepResult particle_step(const epi_params& P, const i
     res.flags = 0; res.o = 0;
     int32_t S = in[src];
     int32_t R = in[in_stride + src];
-    // the last age bin first: its survivors recover (simulate.jl:144) and, through the
-    // circular shift of simulate.jl:145, seed the first term of the infection sum
-    BinOut last = process_bin(P, H - 1, in, in_stride, src, out, out_stride, dst, a, draws, R, res.o, res.flags, pos_out, pos_stride);
-    R += last.ipost;
-    double infsum = draws.gamma(0, P.k[0] * (double)last.ipost, P.theta[0]);   // simulate.jl:40, init.jl:71-78
+    // The last age bin goes first: its survivors recover (simulate.jl:144) and, through the
+    // circular shift of simulate.jl:145, seed term 1 of the infection sum; bin i then feeds term
+    // i + 2.  Iteration `it` therefore handles bin (it == 0 ? H-1 : it-1) and infection term it.
+    double infsum = 0.0;
     int32_t sum_inf = 0;
     double tm = 0.0, tv = 0.0;
+    BinOut last;
+    last.ipost = 0; last.mean = 0.0; last.sd2 = 0.0;
 #pragma unroll 1
-    for (int i = 0; i < H - 1; i++) {
+    for (int it = 0; it < H; it++) {
+        const int i = it == 0 ? H - 1 : it - 1;
         BinOut bo = process_bin(P, i, in, in_stride, src, out, out_stride, dst, a, draws, R, res.o, res.flags, pos_out, pos_stride);
-        tm += bo.mean; tv += bo.sd2;
-        out[(int64_t)(2 + i + 1) * out_stride + dst] = bo.ipost;               // simulate.jl:145
-        sum_inf += bo.ipost;
-        infsum += draws.gamma(i + 1, P.k[i + 1] * (double)bo.ipost, P.theta[i + 1]);
+        if (it == 0) {
+            last = bo;
+            R += bo.ipost;                                                         // simulate.jl:144
+        } else {
+            tm += bo.mean; tv += bo.sd2;
+            out[(int64_t)(2 + it) * out_stride + dst] = bo.ipost;                  // simulate.jl:145
+            sum_inf += bo.ipost;
+        }
+        infsum += draws.gamma(it, P.k[it] * (double)bo.ipost, P.theta[it]);        // simulate.jl:40, init.jl:71-78
     }
     tm += last.mean; tv += last.sd2;
     int64_t denom = P.N - (int64_t)R;

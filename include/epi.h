@@ -220,6 +220,11 @@ void *epi_ctx_stream(epi_ctx *ctx);
  * device until epi_pf_collect. */
 int epi_pf_update_async(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step);
 int epi_pf_collect(epi_ctx *ctx, epi_belief *b, double *loglik, double *ess, uint32_t *flags);
+/* The rejection samplers screen most accept/reject tests in binary32 before
+ * evaluating the defining binary64 expression; results are identical either
+ * way.  enable = 0 forces the binary64 expression everywhere (testing aid,
+ * process-wide). */
+int epi_debug_screen(int enable);
 /* With timing enabled every filter update brackets its fused step kernel with a
  * pair of HIP events on the context's stream; epi_ctx_timing_read waits for the
  * stream, returns the summed kernel time (ms) and the number of launches since

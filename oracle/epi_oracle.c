@@ -253,9 +253,9 @@ static const double fc_tab[10] = {
 static inline double stirling_tail(double k)
 {
     if (k <= 9.0) return fc_tab[(int)k];
-    double kp1 = k + 1.0;
-    double kp1sq = kp1 * kp1;
-    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / kp1;
+    double r = 1.0 / (k + 1.0);
+    double r2 = r * r;
+    return (0.08333333333333333 - (0.002777777777777778 - 0.0007936507936507937 * r2) * r2) * r;
 }
 
 typedef struct {
@@ -300,12 +300,14 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
             r *= (a / (double)x - s);
         }
     } else {
-        double spq = sqrt(nd * pp * qq);
+        /* hat parameters: sqrt and 1/b in binary32 (Hoermann's constants carry 3 digits) */
+        double spq = (double)sqrtf((float)(nd * pp * qq));
         double b = 1.15 + 2.53 * spq;
         double a = -0.0873 + 0.0248 * b + 0.01 * pp;
         double c = nd * pp + 0.5;
-        double vr = 0.92 - 4.2 / b;
-        double alpha = (2.83 + 5.1 / b) * spq;
+        double ib = (double)(1.0f / (float)b);
+        double vr = 0.92 - 4.2 * ib;
+        double alpha = (2.83 + 5.1 * ib) * spq;
         double r = pp / qq;
         double m = floor((nd + 1.0) * pp);
         x = (int64_t)m;                         /* returned only if every attempt fails */
