@@ -229,6 +229,349 @@ __global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const epi_params
 }
 
 // ---------------------------------------------------------------------------
+// k_step_coop: the same fused step as k_step<WEIGH, MODE_PHILOX>, evaluated phase
+// by phase over a workgroup with failed sampler attempts handed to whichever
+// thread is free.  A rejection sampler run per thread costs a wavefront the
+// MAXIMUM attempt count of its 64 lanes; here every draw makes its first attempt
+// in its own thread, draws that were rejected are queued in LDS, and each retry
+// round spreads the queued draws evenly over the 256 threads.  Variates are
+// addressed by (slot, step, bin, attempt), so the result is bit-identical to the
+// per-thread kernel.
+//   A  load the particle, stage (I_i, tested_i) per age bin in LDS, log weight
+//   B  attempt 0 of both binomials of every bin; rejected draws -> queue
+//   C  retry rounds until the queue is empty (attempt r in round r)
+//   D  isolation bookkeeping per bin, attempt 0 of the gamma term; rejected -> queue
+//   E  gamma retry rounds
+//   F  infection sum in bin order, new infections, outputs
+// LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues.
+// ---------------------------------------------------------------------------
+constexpr unsigned int QCAP = 2048;
+
+// push `entry` for every lane that wants to (one LDS atomic per wave); false = queue full
+__device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ULL) return true;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(qn, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (!want) return true;
+    const unsigned int pos = base + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
+    if (pos >= QCAP) return false;
+    q[pos] = entry;
+    return true;
+}
+
+// remaining attempts of a rejection draw, from attempt `att` on (queue overflow only)
+__device__ __forceinline__ int32_t btrs_finish(const BtrsConsts C, const Rng g, uint32_t kind, uint32_t bin, uint32_t att)
+{
+    for (; att < BINOM_MAX_ATTEMPTS; att++) {
+        uint32_t wa, wb;
+        retry_pair(g, kind, bin, att, wa, wb);
+        const int32_t k = btrs_attempt(C, wa, wb);
+        if (k >= 0) return k;
+    }
+    return (int32_t)C.m;
+}
+
+__device__ __forceinline__ double gamma_finish_from(const GammaConsts G, double scale, const Rng g, uint32_t bin, uint32_t att)
+{
+    double v = 1.0;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    float z0 = 0.f, z1 = 0.f;
+    bool have = false;
+    for (; att < GAMMA_MAX_ATTEMPTS; att++) {
+        if (!have || (att & 1u) == 0u) { rng_block(g, K_GAMMA, bin, att >> 1, w); box_muller(w[0], w[1], z0, z1); have = true; }
+        double vv;
+        if (gamma_attempt(G, (att & 1u) ? z1 : z0, (att & 1u) ? w[3] : w[2], vv)) { v = vv; break; }
+    }
+    return gamma_finish(G, v, scale, g, bin);
+}
+
+template <bool WEIGH>
+__global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const epi_params P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int H = P.H, D = P.D;
+    int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][TPB]: (I_i, tested_i) -> (sympt_i, pos_i)
+    int* slot_words = reinterpret_cast<int*>(smem);
+    double* gslots = reinterpret_cast<double*>(smem);                              // [H][TPB]: gamma term of the bin's survivors
+    unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * TPB * 8);
+    unsigned short* q1 = q0 + QCAP;
+    unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP);                 // qn[0], qn[1]
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 2);     // [TPB/64]
+
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * TPB;
+    const int64_t m = base + tid;
+    const bool active = m < A.n;
+    const int64_t src = active ? (A.anc ? (int64_t)A.anc[m] : m) : 0;
+    const double a = active ? (A.a_dev ? A.a_dev[m * A.a_row_stride + A.a_col] : A.a) : 0.0;
+    const Rng g = rng_make(A.seed, A.slot0 + (uint64_t)m, A.step);
+    const bool screen = A.screen != 0;
+    const int32_t* __restrict__ in = A.in;
+    int32_t* __restrict__ out = A.out;
+    const int64_t is = A.in_stride, os = A.out_stride;
+    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; }
+    unsigned int flags = 0;
+    int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
+    unsigned long long code = 0ULL;
+
+    // ---- A: stage the bins, observation moments -----------------------------------
+    if (active) {
+        S = in[src]; R = in[is + src]; R_pre = R;
+        double tm = 0.0, tv = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < H; i++) {
+            const int32_t Ii = in[(int64_t)(2 + i) * is + src];
+            int32_t already = 0;
+            if (D > 0 && i >= 1)
+                for (int r = 0; r < D; r++) already += in[(int64_t)tests_row(H, r, i) * is + src];
+            const double ntf = __builtin_floor((double)(Ii - already) * a);        // simulate.jl:78
+            const int32_t nt = (int32_t)ntf;
+            if (nt < 0) flags |= EPI_F_NEG_NT;
+            slots[i * TPB + tid] = make_int2(Ii, nt);
+            suminf_pre += Ii;
+            if constexpr (WEIGH) {
+                const double pi = P.p[i];
+                tm += ntf * pi;                                                    // POMDPsInterface.jl:19
+                const double sd = __builtin_sqrt(ntf * pi * (1.0 - pi));
+                tv += sd * sd;                                                     // POMDPsInterface.jl:20
+            }
+        }
+        if constexpr (WEIGH) {
+            const double lw = log_weight(tm, tv, A.o);
+            A.lw[m] = lw;
+            code = order_code(lw);
+        }
+    }
+    __syncthreads();
+
+    // ---- B: attempt 0 of both binomials of every bin --------------------------------
+#pragma unroll 1
+    for (int i = 0; i < H; i++) {
+        bool fail0 = false, fail1 = false;
+        if (active) {
+            int2 nn = slots[i * TPB + tid];
+            uint32_t w[4];
+            rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
+#pragma unroll 1
+            for (int j = 0; j < 2; j++) {
+                const int32_t n = j ? nn.y : nn.x;
+                const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];
+                int32_t x; double pp; bool flip;
+                const int cls = binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
+                bool fail = false;
+                if (cls == BINOM_INVERSION) x = binom_inversion(n, pp, wa);
+                else if (cls == BINOM_REJECTION) {
+                    const BtrsConsts C = btrs_consts(n, pp, screen);
+                    x = btrs_attempt(C, wa, wb);
+                    fail = x < 0;
+                }
+                const int32_t res = fail ? n : (flip ? n - x : x);                 // a rejected draw keeps n for its retry
+                if (j) { nn.y = res; fail1 = fail; } else { nn.x = res; fail0 = fail; }
+            }
+            slots[i * TPB + tid] = nn;
+        }
+        const unsigned short e0 = (unsigned short)(tid | (i << 8));
+        const bool ok0 = q_push(fail0, e0, q0, &qn[0]);
+        const bool ok1 = q_push(fail1, (unsigned short)(e0 | (1 << 14)), q0, &qn[0]);
+        if ((fail0 && !ok0) || (fail1 && !ok1)) {                                  // queue full: finish here
+            int2 nn = slots[i * TPB + tid];
+            for (int j = 0; j < 2; j++) {
+                if (j ? (fail1 && !ok1) : (fail0 && !ok0)) {
+                    const int32_t n = j ? nn.y : nn.x;
+                    int32_t x; double pp; bool flip;
+                    binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
+                    const int32_t k = btrs_finish(btrs_consts(n, pp, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
+                    slot_words[(i * TPB + tid) * 2 + j] = flip ? n - k : k;
+                }
+            }
+        }
+    }
+
+    // ---- C: binomial retry rounds ------------------------------------------------------
+    {
+        int cur = 0;
+#pragma unroll 1
+        for (uint32_t round = 1; round < BINOM_MAX_ATTEMPTS; round++) {
+            __syncthreads();
+            const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
+            __syncthreads();
+            if (cnt == 0u) break;
+            if (tid == 0) qn[cur ^ 1] = 0u;
+            __syncthreads();
+            const unsigned short* q = cur ? q1 : q0;
+            unsigned short* qnext = cur ? q0 : q1;
+#pragma unroll 1
+            for (unsigned int e = tid; e < cnt; e += TPB) {
+                const unsigned short entry = q[e];
+                const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
+                const int32_t n = slot_words[(i * TPB + t) * 2 + j];
+                int32_t x; double pp; bool flip;
+                binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
+                const BtrsConsts C = btrs_consts(n, pp, screen);
+                const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
+                uint32_t wa, wb;
+                retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
+                int32_t k = btrs_attempt(C, wa, wb);
+                const bool fail = k < 0;
+                const bool pushed = q_push(fail, entry, qnext, &qn[cur ^ 1]);
+                if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);
+                if (k >= 0) slot_words[(i * TPB + t) * 2 + j] = flip ? n - k : k;
+            }
+            cur ^= 1;
+        }
+    }
+    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; }
+    __syncthreads();
+
+    // ---- D: isolation bookkeeping and attempt 0 of the gamma terms -------------------------
+    // iteration `it` handles bin (it == 0 ? H-1 : it-1), whose survivors seed infection term `it`
+    // (the circular shift of simulate.jl:145)
+    int32_t sum_inf = 0;
+#pragma unroll 1
+    for (int it = 0; it < H; it++) {
+        const int i = it == 0 ? H - 1 : it - 1;
+        bool gfail = false;
+        if (active) {
+            const int2 sp = slots[i * TPB + tid];
+            const int32_t sympt = sp.x, pos = sp.y;
+            int32_t Ii = in[(int64_t)(2 + i) * is + src];
+            double pr = (double)sympt / (double)Ii;                                // simulate.jl:104
+            if (pr != pr) pr = 0.0;                                                // simulate.jl:105
+            const double om = 1.0 - pr;
+            R += sympt; Ii -= sympt;                                               // simulate.jl:107-108
+            for (int r = 0; r <= D; r++) {                                         // simulate.jl:110-126
+                int32_t tv;
+                if (r == D) tv = pos;
+                else tv = (i >= 1) ? in[(int64_t)tests_row(H, r, i) * is + src] : 0;
+                const int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
+                if (r == 0) { R += ts; Ii -= ts; }
+                else if (i + 1 < H) out[(int64_t)tests_row(H, r - 1, i + 1) * os + m] = ts;
+            }
+            if (Ii < 0) flags |= EPI_F_NEG_I;                                      // simulate.jl:117
+            o_sum += pos;
+            if (it == 0) R += Ii;                                                  // simulate.jl:144
+            else { out[(int64_t)(2 + it) * os + m] = Ii; sum_inf += Ii; }          // simulate.jl:145
+            const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78
+            if (gamma_is_zero(shape)) gslots[i * TPB + tid] = 0.0;
+            else {
+                const GammaConsts G = gamma_consts(shape, screen);
+                uint32_t w[4];
+                rng_block(g, K_GAMMA, (uint32_t)it, 0, w);
+                float z0, z1;
+                box_muller(w[0], w[1], z0, z1);
+                double v;
+                if (gamma_attempt(G, z0, w[2], v)) gslots[i * TPB + tid] = gamma_finish(G, v, P.theta[it], g, (uint32_t)it);
+                else { slots[i * TPB + tid] = make_int2(Ii, 0); gfail = true; }
+            }
+        }
+        const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[0]);
+        if (gfail && !gpushed) {
+            const int32_t Ii = slots[i * TPB + tid].x;
+            gslots[i * TPB + tid] = gamma_finish_from(gamma_consts(P.k[it] * (double)Ii, screen), P.theta[it], g, (uint32_t)it, 1u);
+        }
+    }
+
+    // ---- E: gamma retry rounds ---------------------------------------------------------------
+    {
+        int cur = 0;
+#pragma unroll 1
+        for (uint32_t round = 1; round < GAMMA_MAX_ATTEMPTS; round++) {
+            __syncthreads();
+            const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
+            __syncthreads();
+            if (cnt == 0u) break;
+            if (tid == 0) qn[cur ^ 1] = 0u;
+            __syncthreads();
+            const unsigned short* q = cur ? q1 : q0;
+            unsigned short* qnext = cur ? q0 : q1;
+#pragma unroll 1
+            for (unsigned int e = tid; e < cnt; e += TPB) {
+                const unsigned short entry = q[e];
+                const int t = entry & 255, it = entry >> 8;
+                const int i = it == 0 ? H - 1 : it - 1;
+                const int32_t Ii = slots[i * TPB + t].x;
+                const GammaConsts G = gamma_consts(P.k[it] * (double)Ii, screen);
+                const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
+                uint32_t w[4];
+                rng_block(gt, K_GAMMA, (uint32_t)it, round >> 1, w);
+                float z0, z1;
+                box_muller(w[0], w[1], z0, z1);
+                double v;
+                const bool ok = gamma_attempt(G, (round & 1u) ? z1 : z0, (round & 1u) ? w[3] : w[2], v);
+                const bool pushed = q_push(!ok, entry, qnext, &qn[cur ^ 1]);
+                if (ok) gslots[i * TPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
+                else if (!pushed) gslots[i * TPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
+            }
+            cur ^= 1;
+        }
+    }
+
+    // ---- F: infection sum in bin order, new infections, outputs --------------------------------
+    if (active) {
+        double infsum = 0.0;
+#pragma unroll 1
+        for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * TPB + tid];   // simulate.jl:38-41
+        const int64_t denom = P.N - (int64_t)R;
+        int32_t newi = 0;
+        if (denom <= 0) flags |= EPI_F_BAD_DENOM;
+        else newi = (int32_t)__builtin_floor(((double)S / (double)denom) * infsum);             // simulate.jl:42-44
+        out[(int64_t)2 * os + m] = newi;                                                        // simulate.jl:147
+        out[m] = S - newi;                                                                      // simulate.jl:148
+        out[os + m] = R;
+        if (A.o_out) A.o_out[m] = o_sum;
+        if (A.newinf_out) A.newinf_out[m] = newi;
+        if (A.r_out) {
+            const double ap = A.a_prev_dev ? A.a_prev_dev[m * A.a_row_stride + A.a_prev_col] : A.a_prev;
+            A.r_out[m] = reward_of(P, sum_inf + newi, a, ap);
+        }
+        if (A.hist) { A.hist[m] = S; A.hist[A.n + m] = suminf_pre; A.hist[2 * A.n + m] = R_pre; A.hist[3 * A.n + m] = o_sum; }
+    }
+    unsigned int wf = flags;
+    for (int d = 32; d >= 1; d >>= 1) wf |= __shfl_down(wf, d, 64);
+    if ((tid & 63) == 0 && wf) atomicOr(&A.scal->flags, wf);
+    if constexpr (WEIGH) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            unsigned long long o = shfl_down_u64(code, d);
+            code = o > code ? o : code;
+        }
+        if ((tid & 63) == 0) s_max[tid >> 6] = code;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long c = s_max[0];
+            for (int w = 1; w < TPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
+            atomicMax(&A.scal->lwmax_bits, c);
+        }
+    }
+}
+
+static size_t coop_lds_bytes(int H) { return (size_t)H * TPB * 8 + 2 * QCAP * sizeof(unsigned short) + 2 * sizeof(unsigned int) + (TPB / 64) * sizeof(unsigned long long); }
+
+static int g_coop = 1;       // see epi_debug_step_impl
+
+// launch the Philox-driven step with the selected implementation
+template <bool WEIGH>
+static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
+{
+    const dim3 grid((unsigned)ceil_div(A.n, TPB)), blk(TPB);
+    if (g_coop) {
+        const size_t lds = coop_lds_bytes(c->P.H);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        k_step_coop<WEIGH><<<grid, blk, lds, c->stream>>>(A, c->P);
+    } else {
+        k_step<WEIGH, MODE_PHILOX><<<grid, blk, 0, c->stream>>>(A, c->P);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // fixed-point weights and their prefix sums
 //   wq_i = floor(exp(lw_i - lwmax) * 2^F)
 // ---------------------------------------------------------------------------
@@ -842,8 +1185,7 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
     if (o_out) { if (dob.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.o_out = dob.as<int32_t>(); }
     if (r_out) { if (dr.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.r_out = dr.as<double>(); }
     if (new_inf_out) { if (dni.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.newinf_out = dni.as<int32_t>(); }
-    k_step<false, MODE_PHILOX><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
-    HIPCHECK(hipGetLastError());
+    HIPCHECK(launch_step<false>(c, A));
     std::vector<int32_t> h((size_t)n);
     if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), dob.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
     if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), dni.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
@@ -1037,8 +1379,7 @@ int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, i
         A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
         if (hist) A.hist = dhist.as<int32_t>() + (size_t)t * 4 * (size_t)n;
         if (rew) A.r_out = drew.as<double>() + (size_t)t * (size_t)n;
-        k_step<false, MODE_PHILOX><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
-        HIPCHECK(hipGetLastError());
+        HIPCHECK(launch_step<false>(c, A));
         b->cur ^= 1; b->has_anc = false;
     }
     if (hist) {
@@ -1090,8 +1431,7 @@ static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
         c->timed.emplace_back(e0, e1);
     }
     HIPCHECK(hipEventRecord(e0, c->stream));
-    k_step<true, MODE_PHILOX><<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
-    HIPCHECK(hipGetLastError());
+    HIPCHECK(launch_step<true>(c, A));
     HIPCHECK(hipEventRecord(e1, c->stream));
     if (!c->timing) c->ev_valid = true;
     b->seed = seed; b->step = step;
@@ -1153,6 +1493,12 @@ int epi_pf_update(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed,
     int rc = epi_pf_update_async(c, b, a, o, seed, step);
     if (rc) return rc;
     return epi_pf_collect(c, b, loglik, ess, flags);
+}
+
+int epi_debug_step_impl(int cooperative)
+{
+    g_coop = cooperative != 0;
+    return EPI_OK;
 }
 
 int epi_debug_screen(int enable)

@@ -239,7 +239,7 @@ __device__ __forceinline__ float f_stirling_tail(float kp1)
 // The defining acceptance test of the transformed-rejection sampler (Hoermann 1993, step 3):
 // log(v alpha / (a/us^2 + b)) <= log f(k) - log f(m), with Stirling-corrected log factorials.
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __attribute__((noinline))
+__device__ __forceinline__
 #else
 static inline
 #endif
@@ -255,57 +255,149 @@ bool btrs_accept_exact(double nd, double pp, double qq, double m, double kd, dou
     return lv <= ub;
 }
 
+// A Binomial(n, p) draw is split into pieces so that a kernel can either loop over attempts
+// per thread (binomial_draw) or hand failed attempts to other threads:
+//   binom_classify : trivial result / inversion / rejection, and the folded probability
+//   binom_inversion: n min(p,1-p) < 10, one uniform, always completes
+//   btrs_consts    : per-draw constants of the rejection sampler
+//   btrs_attempt   : one attempt from one word pair: accepted k, or -1
+enum { BINOM_DONE = 0, BINOM_INVERSION = 1, BINOM_REJECTION = 2 };
+
+EPI_HD int binom_classify(int32_t n, double p, int32_t& result, double& pp, bool& flip)
+{
+    result = 0; pp = 0.0; flip = false;
+    if (n <= 0 || !(p > 0.0)) return BINOM_DONE;
+    if (p >= 1.0) { result = n; return BINOM_DONE; }
+    flip = p > 0.5;
+    pp = flip ? 1.0 - p : p;
+    return ((double)n * pp < 10.0) ? BINOM_INVERSION : BINOM_REJECTION;
+}
+
+EPI_HD int32_t binom_inversion(int32_t n, double pp, uint32_t wa)
+{
+    const double nd = (double)n, qq = 1.0 - pp;
+    const double s = pp / qq;
+    const double a = (nd + 1.0) * s;
+    double r = s_exp(nd * s_log(qq));
+    double u = u01(wa);
+    int32_t x = 0;
+    while (u > r && x < n) {
+        u -= r;
+        x += 1;
+        r *= (a / (double)x - s);
+    }
+    return x;
+}
+
+struct BtrsConsts {
+    double nd, pp, qq, a, b, c, vr, alpha, m;
+#ifdef EPI_HAVE_SCREEN
+    // constants of the binary32 screens.  With m1 = m+1, n1 = n-m+1, dk = k-m:
+    //   ub = -dk LA - dk(dk+1/2)/n1 - dk(dk-1/2)/m1 - (n-k+1/2) g(-dk/n1) - (k+1/2) g(dk/m1)
+    //        + fc(m) + fc(n-m) - fc(k) - fc(n-k),      g(t) = log1p(t) - t,
+    //   LA = log((m+1) q / (p n1)) = log1p((1 - frac((n+1)p) - p) / (p n1))
+    // which is the defining expression (btrs_accept_exact) rearranged so that no large terms cancel.
+    double cfl;
+    float m1f, n1f, rm1, rn1, LA, fcm, af, bf, alf, cfr;
+    bool scr;
+#endif
+};
+
+EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, bool screen)
+{
+    BtrsConsts C;
+    C.nd = (double)n; C.pp = pp; C.qq = 1.0 - pp;
+    // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
+    const double spq = (double)__builtin_sqrtf((float)(C.nd * pp * C.qq));
+    C.b = 1.15 + 2.53 * spq;
+    C.a = -0.0873 + 0.0248 * C.b + 0.01 * pp;
+    C.c = C.nd * pp + 0.5;
+    const double ib = (double)(1.0f / (float)C.b);
+    C.vr = 0.92 - 4.2 * ib;
+    C.alpha = (2.83 + 5.1 * ib) * spq;
+    const double mt = (C.nd + 1.0) * pp;
+    C.m = __builtin_floor(mt);
+#ifdef EPI_HAVE_SCREEN
+    C.scr = screen && C.nd < 16777216.0;
+    C.m1f = (float)(C.m + 1.0); C.n1f = (float)(C.nd - C.m + 1.0);
+    C.rm1 = f_rcp(C.m1f); C.rn1 = f_rcp(C.n1f);
+    const float dA = (float)(1.0 - (mt - C.m) - pp) * f_rcp((float)pp * C.n1f);
+    C.LA = dA + f_log1p_minus(dA);
+    C.fcm = f_stirling_tail(C.m1f) + f_stirling_tail(C.n1f);
+    C.af = (float)C.a; C.bf = (float)C.b; C.alf = (float)C.alpha;
+    C.cfl = __builtin_floor(C.c);
+    C.cfr = (float)(C.c - C.cfl);
+#else
+    (void)screen;
+#endif
+    return C;
+}
+
+// one attempt: returns the accepted k (>= 0) or -1
+EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
+{
+    const double u = u01(wa) - 0.5;
+    const double v = u01(wb);
+    const double us = 0.5 - __builtin_fabs(u);
+    double kd = 0.0;
+    bool have_k = false;
+#ifdef EPI_HAVE_SCREEN
+    if (C.scr) {
+        // k = floor((2a/us + b) u + c) estimated in binary32; trusted when the value is
+        // further from an integer than many times its error bound
+        const float t = __builtin_fmaf(__builtin_fmaf(2.0f * C.af, f_rcp((float)us), C.bf), (float)u, C.cfr);
+        const float tf = __builtin_floorf(t);
+        const float fr = t - tf;
+        const float dl = __builtin_fmaf(__builtin_fabsf(t) + C.bf, 4e-6f, 1e-3f);
+        if (fr > dl && fr < 1.0f - dl) { kd = C.cfl + (double)tf; have_k = true; }
+    }
+#endif
+    if (!have_k) kd = __builtin_floor((2.0 * C.a / us + C.b) * u + C.c);
+    if (kd < 0.0 || kd > C.nd) return -1;
+    if (us >= 0.07 && v <= C.vr) return (int32_t)kd;
+#ifdef EPI_HAVE_SCREEN
+    if (C.scr && kd >= 2.0 && C.nd - kd >= 2.0) {
+        const float dk = (float)(kd - C.m);
+        const float k1f = C.m1f + dk, nk1f = C.n1f - dk;
+        const float usf = (float)us;
+        const float lv = f_ln((float)v * C.alf * f_rcp(__builtin_fmaf(C.af, f_rcp(usf * usf), C.bf)));
+        const float t_a = dk * C.LA;
+        const float t_l1 = dk * (dk + 0.5f) * C.rn1, t_l2 = dk * (dk - 0.5f) * C.rm1;
+        const float t_g1 = (nk1f - 0.5f) * f_log1p_minus(-dk * C.rn1), t_g2 = (k1f - 0.5f) * f_log1p_minus(dk * C.rm1);
+        const float t_fc = f_stirling_tail(k1f) + f_stirling_tail(nk1f);
+        const float ub = C.fcm - t_fc - t_a - t_l1 - t_l2 - t_g1 - t_g2;
+        const float mag = __builtin_fabsf(lv) + __builtin_fabsf(t_a) + t_l1 + t_l2 - t_g1 - t_g2 + C.fcm + t_fc;
+        const float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
+        const float diff = lv - ub;
+        if (diff < -guard) return (int32_t)kd;
+        if (diff > guard) return -1;
+    }
+#endif
+    return btrs_accept_exact(C.nd, C.pp, C.qq, C.m, kd, v, us, C.a, C.b, C.alpha) ? (int32_t)kd : -1;
+}
+
+// Word pair of attempt `att` (>= 1) of a retry stream: block (att-1)/2, words (0,1) or (2,3).
+EPI_HD void retry_pair(const Rng& g, uint32_t retry_kind, uint32_t bin, uint32_t att, uint32_t& wa, uint32_t& wb)
+{
+    uint32_t w[4];
+    rng_block(g, retry_kind, bin, (att - 1u) >> 1, w);
+    const bool half = ((att - 1u) & 1u) != 0u;
+    wa = half ? w[2] : w[0];
+    wb = half ? w[3] : w[1];
+}
+
 // fa, fb: the attempt-0 word pair; attempts a >= 1 come from blocks of retry_kind.
-// screen: allow the binary32 screen (device only; never changes the result).
+// screen: allow the binary32 screens (device only; never changes the result).
 EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
                              const Rng& g, uint32_t retry_kind, uint32_t bin, bool screen = true)
 {
-    if (n <= 0 || !(p > 0.0)) return 0;
-    if (p >= 1.0) return n;
-    const bool flip = p > 0.5;
-    const double pp = flip ? 1.0 - p : p;
-    const double qq = 1.0 - pp;
-    const double nd = (double)n;
-    int32_t x;
-    if (nd * pp < 10.0) {
-        double s = pp / qq;
-        double a = (nd + 1.0) * s;
-        double r = s_exp(nd * s_log(qq));
-        double u = u01(fa);
-        x = 0;
-        while (u > r && x < n) {
-            u -= r;
-            x += 1;
-            r *= (a / (double)x - s);
-        }
-    } else {
-        // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
-        const double spq = (double)__builtin_sqrtf((float)(nd * pp * qq));
-        const double b = 1.15 + 2.53 * spq;
-        const double a = -0.0873 + 0.0248 * b + 0.01 * pp;
-        const double c = nd * pp + 0.5;
-        const double ib = (double)(1.0f / (float)b);
-        const double vr = 0.92 - 4.2 * ib;
-        const double alpha = (2.83 + 5.1 * ib) * spq;
-        const double mt = (nd + 1.0) * pp;
-        const double m = __builtin_floor(mt);
-        x = (int32_t)m;
-#ifdef EPI_HAVE_SCREEN
-        // per-draw constants of the screens.  With m1 = m+1, n1 = n-m+1, dk = k-m:
-        //   ub = -dk LA - dk(dk+1/2)/n1 - dk(dk-1/2)/m1 - (n-k+1/2) g(-dk/n1) - (k+1/2) g(dk/m1)
-        //        + fc(m) + fc(n-m) - fc(k) - fc(n-k),      g(t) = log1p(t) - t,
-        //   LA = log((m+1) q / (p n1)) = log1p((1 - frac((n+1)p) - p) / (p n1))
-        // which is the defining expression (btrs_accept_exact) rearranged so that no large terms cancel.
-        const bool scr = screen && nd < 16777216.0;
-        const float m1f = (float)(m + 1.0), n1f = (float)(nd - m + 1.0);
-        const float rm1 = f_rcp(m1f), rn1 = f_rcp(n1f);
-        const float dA = (float)(1.0 - (mt - m) - pp) * f_rcp((float)pp * n1f);
-        const float LA = dA + f_log1p_minus(dA);
-        const float fcm = f_stirling_tail(m1f) + f_stirling_tail(n1f);
-        const float af = (float)a, bf = (float)b, alf = (float)alpha;
-        const double cfl = __builtin_floor(c);
-        const float cfr = (float)(c - cfl);
-#endif
+    int32_t x; double pp; bool flip;
+    const int cls = binom_classify(n, p, x, pp, flip);
+    if (cls == BINOM_DONE) return x;
+    if (cls == BINOM_INVERSION) x = binom_inversion(n, pp, fa);
+    else {
+        const BtrsConsts C = btrs_consts(n, pp, screen);
+        x = (int32_t)C.m;                    // returned only if every attempt fails
         uint32_t w[4] = {0u, 0u, fa, fb};
         // attempt j-1 takes words (2,3) of its block when j is odd and words (0,1) when j is even;
         // the attempt-0 pair sits in words (2,3) of the initial contents
@@ -313,46 +405,8 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
         for (uint32_t j = 1; j <= BINOM_MAX_ATTEMPTS; j++) {
             const uint32_t half = j & 1u;
             if (half == 0u) rng_block(g, retry_kind, bin, (j - 2u) >> 1, w);
-            const uint32_t wa = half ? w[2] : w[0];
-            const uint32_t wb = half ? w[3] : w[1];
-            const double u = u01(wa) - 0.5;
-            const double v = u01(wb);
-            const double us = 0.5 - __builtin_fabs(u);
-            double kd;
-            bool have_k = false;
-#ifdef EPI_HAVE_SCREEN
-            if (scr) {
-                // k = floor((2a/us + b) u + c) estimated in binary32; trusted when the value is
-                // further from an integer than many times its error bound
-                const float t = __builtin_fmaf(__builtin_fmaf(2.0f * af, f_rcp((float)us), bf), (float)u, cfr);
-                const float tf = __builtin_floorf(t);
-                const float fr = t - tf;
-                const float dl = __builtin_fmaf(__builtin_fabsf(t) + bf, 4e-6f, 1e-3f);
-                if (fr > dl && fr < 1.0f - dl) { kd = cfl + (double)tf; have_k = true; }
-            }
-#endif
-            if (!have_k) kd = __builtin_floor((2.0 * a / us + b) * u + c);
-            if (kd < 0.0 || kd > nd) continue;
-            if (us >= 0.07 && v <= vr) { x = (int32_t)kd; break; }
-#ifdef EPI_HAVE_SCREEN
-            if (scr && kd >= 2.0 && nd - kd >= 2.0) {
-                const float dk = (float)(kd - m);
-                const float k1f = m1f + dk, nk1f = n1f - dk;
-                const float usf = (float)us;
-                const float lv = f_ln((float)v * alf * f_rcp(__builtin_fmaf(af, f_rcp(usf * usf), bf)));
-                const float t_a = dk * LA;
-                const float t_l1 = dk * (dk + 0.5f) * rn1, t_l2 = dk * (dk - 0.5f) * rm1;
-                const float t_g1 = (nk1f - 0.5f) * f_log1p_minus(-dk * rn1), t_g2 = (k1f - 0.5f) * f_log1p_minus(dk * rm1);
-                const float t_fc = f_stirling_tail(k1f) + f_stirling_tail(nk1f);
-                const float ub = fcm - t_fc - t_a - t_l1 - t_l2 - t_g1 - t_g2;
-                const float mag = __builtin_fabsf(lv) + __builtin_fabsf(t_a) + t_l1 + t_l2 - t_g1 - t_g2 + fcm + t_fc;
-                const float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
-                const float diff = lv - ub;
-                if (diff < -guard) { x = (int32_t)kd; break; }
-                if (diff > guard) continue;
-            }
-#endif
-            if (btrs_accept_exact(nd, pp, qq, m, kd, v, us, a, b, alpha)) { x = (int32_t)kd; break; }
+            const int32_t k = btrs_attempt(C, half ? w[2] : w[0], half ? w[3] : w[1]);
+            if (k >= 0) { x = k; break; }
         }
     }
     return flip ? n - x : x;
@@ -360,71 +414,99 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
 
 // ---- Gamma(shape, scale) --------------------------------------------------------
 // Marsaglia-Tsang (2000); shape < 1 boosted by U^(1/shape); shape < 2^-30 -> 0.
+//   gamma_consts  : per-draw constants
+//   gamma_attempt : one attempt from one normal and one word: true if accepted
+//   gamma_finish  : boost and scale of an accepted attempt
 constexpr uint32_t GAMMA_MAX_ATTEMPTS = 512u;
+
+struct GammaConsts {
+    double shape, d, c;
+    bool boost, screen;
+};
+
+EPI_HD bool gamma_is_zero(double shape) { return !(shape >= 0x1p-30); }
+
+EPI_HD GammaConsts gamma_consts(double shape, bool screen)
+{
+    GammaConsts G;
+    G.shape = shape;
+    G.boost = shape < 1.0;
+    const double al = G.boost ? shape + 1.0 : shape;
+    G.d = al - 0.3333333333333333;
+    G.c = 1.0 / __builtin_sqrt(9.0 * G.d);
+    G.screen = screen;
+    return G;
+}
+
+EPI_HD bool gamma_attempt(const GammaConsts& G, float xf, uint32_t wu, double& v)
+{
+    const double x = (double)xf;
+    const double u = u01(wu);
+    const double t = 1.0 + G.c * x;
+    if (!(t > 0.0)) return false;
+    const double vv = t * t * t;
+    const double x2 = x * x;
+    v = vv;
+    if (u < 1.0 - 0.0331 * (x2 * x2)) return true;
+#ifdef EPI_HAVE_SCREEN
+    if (G.screen) {
+        // x^2/2 + d (1 - v + log v) = 3 d (log1p(t) - t + t^2/2 - t^3/3), t = c x  (since 9 d c^2 = 1)
+        const float tf = (float)G.c * xf, df = (float)G.d;
+        if (tf > -0.9f) {
+            const float t2 = tf * tf;
+            float q = 0.1f;
+            q = __builtin_fmaf(q, tf, -0.111111111f);
+            q = __builtin_fmaf(q, tf, 0.125f);
+            q = __builtin_fmaf(q, tf, -0.142857143f);
+            q = __builtin_fmaf(q, tf, 0.166666667f);
+            q = __builtin_fmaf(q, tf, -0.2f);
+            q = __builtin_fmaf(q, tf, 0.25f);
+            const float ser = -(t2 * t2) * q;                                 // log1p(t) - t + t^2/2 - t^3/3
+            const float l1p = f_ln(1.0f + tf);
+            const float big = l1p - tf + 0.5f * t2 - 0.333333333f * t2 * tf;
+            const float magb = __builtin_fabsf(l1p) + __builtin_fabsf(tf) + 0.5f * t2 + 0.333333333f * __builtin_fabsf(t2 * tf);
+            const bool small = __builtin_fabsf(tf) <= 0.125f;
+            const float rhs = 3.0f * df * (small ? ser : big);
+            const float lu = f_ln((float)u);
+            const float mag = __builtin_fabsf(lu) + 3.0f * df * (small ? __builtin_fabsf(ser) : magb);
+            const float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
+            const float diff = lu - rhs;
+            if (diff < -guard) return true;
+            if (diff > guard) return false;
+        }
+    }
+#endif
+    return s_log(u) < 0.5 * x2 + G.d * (1.0 - vv + s_log(vv));
+}
+
+EPI_HD double gamma_finish(const GammaConsts& G, double v, double scale, const Rng& g, uint32_t bin)
+{
+    double gval = G.d * v;
+    if (G.boost) {
+        uint32_t wb[4];
+        rng_block(g, K_BOOST, bin, 0, wb);
+        gval = gval * s_exp(s_log(u01(wb[0])) / G.shape);
+    }
+    return gval * scale;
+}
 
 EPI_HD double gamma_draw(double shape, double scale, const Rng& g, uint32_t bin, bool screen = true)
 {
-    if (!(shape >= 0x1p-30)) return 0.0;
-    const bool boost = shape < 1.0;
-    const double al = boost ? shape + 1.0 : shape;
-    const double d = al - 0.3333333333333333;
-    const double c = 1.0 / __builtin_sqrt(9.0 * d);
-    double v = 1.0;
+    if (gamma_is_zero(shape)) return 0.0;
+    const GammaConsts G = gamma_consts(shape, screen);
+    double v = 1.0;                            // used only if every attempt fails
     uint32_t w[4] = {0u, 0u, 0u, 0u};
     float z0 = 0.f, z1 = 0.f;
-#ifdef EPI_HAVE_SCREEN
-    const float cf = (float)c, df = (float)d;
-#endif
+#pragma unroll 1
     for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
         if ((att & 1u) == 0u) {
             rng_block(g, K_GAMMA, bin, att >> 1, w);
             box_muller(w[0], w[1], z0, z1);
         }
-        const float xf = (att & 1u) ? z1 : z0;
-        double x = (double)xf;
-        double u = u01((att & 1u) ? w[3] : w[2]);
-        double t = 1.0 + c * x;
-        if (!(t > 0.0)) continue;
-        double vv = t * t * t;
-        double x2 = x * x;
-        if (u < 1.0 - 0.0331 * (x2 * x2)) { v = vv; break; }
-#ifdef EPI_HAVE_SCREEN
-        if (screen) {
-            // x^2/2 + d (1 - v + log v) = 3 d (log1p(t) - t + t^2/2 - t^3/3), t = c x  (since 9 d c^2 = 1)
-            float tf = cf * xf;
-            if (tf > -0.9f) {
-                float t2 = tf * tf;
-                float q = 0.1f;
-                q = __builtin_fmaf(q, tf, -0.111111111f);
-                q = __builtin_fmaf(q, tf, 0.125f);
-                q = __builtin_fmaf(q, tf, -0.142857143f);
-                q = __builtin_fmaf(q, tf, 0.166666667f);
-                q = __builtin_fmaf(q, tf, -0.2f);
-                q = __builtin_fmaf(q, tf, 0.25f);
-                float ser = -(t2 * t2) * q;                                   // log1p(t) - t + t^2/2 - t^3/3
-                float l1p = f_ln(1.0f + tf);
-                float big = l1p - tf + 0.5f * t2 - 0.333333333f * t2 * tf;
-                float magb = __builtin_fabsf(l1p) + __builtin_fabsf(tf) + 0.5f * t2 + 0.333333333f * __builtin_fabsf(t2 * tf);
-                bool small = __builtin_fabsf(tf) <= 0.125f;
-                float rhs = 3.0f * df * (small ? ser : big);
-                float lu = f_ln((float)u);
-                float mag = __builtin_fabsf(lu) + 3.0f * df * (small ? __builtin_fabsf(ser) : magb);
-                float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
-                float diff = lu - rhs;
-                if (diff < -guard) { v = vv; break; }
-                if (diff > guard) continue;
-            }
-        }
-#endif
-        if (s_log(u) < 0.5 * x2 + d * (1.0 - vv + s_log(vv))) { v = vv; break; }
+        double vv;
+        if (gamma_attempt(G, (att & 1u) ? z1 : z0, (att & 1u) ? w[3] : w[2], vv)) { v = vv; break; }
     }
-    double gval = d * v;
-    if (boost) {
-        uint32_t wb[4];
-        rng_block(g, K_BOOST, bin, 0, wb);
-        gval = gval * s_exp(s_log(u01(wb[0])) / shape);
-    }
-    return gval * scale;
+    return gamma_finish(G, v, scale, g, bin);
 }
 
 // 53-bit uniform in [0,1) of the systematic resampler for (seed, step)

@@ -225,6 +225,10 @@ int epi_pf_collect(epi_ctx *ctx, epi_belief *b, double *loglik, double *ess, uin
  * way.  enable = 0 forces the binary64 expression everywhere (testing aid,
  * process-wide). */
 int epi_debug_screen(int enable);
+/* Two implementations of the Philox-driven step kernel give identical results:
+ * cooperative = 1 (default) hands rejected sampler attempts to idle threads of
+ * the workgroup, 0 loops per thread.  Testing aid, process-wide. */
+int epi_debug_step_impl(int cooperative);
 /* With timing enabled every filter update brackets its fused step kernel with a
  * pair of HIP events on the context's stream; epi_ctx_timing_read waits for the
  * stream, returns the summed kernel time (ms) and the number of launches since
