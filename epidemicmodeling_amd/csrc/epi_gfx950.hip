@@ -77,6 +77,7 @@ struct epi_ctx {
     epi_params P;
     bool have_params = false;
     DevScalars* d_scal = nullptr;
+    DevParams* d_params = nullptr;      // parameters + derived per-bin constants, as the kernels read them
     long long* d_sums = nullptr;        // 2 + H + (D+1) H column sums
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -168,8 +169,9 @@ struct StepArgs {
 enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
 
 template <bool WEIGH, int MODE>
-__global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const epi_params P)
+__global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const DevParams* __restrict__ Dp)
 {
+    const epi_params& P = Dp->P;
     __shared__ unsigned long long s_max[TPB / 64];
     const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
     unsigned long long code = 0ULL;       // below every real code
@@ -187,10 +189,10 @@ __global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const epi_params
             InjectedDraws d{A.inj_sympt, A.inj_pos, A.inj_gam, A.n, m};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else if constexpr (MODE == MODE_RECORD) {
-            RecordingDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
+            RecordingDraws d{PhiloxDraws{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0.f, 0u}, A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else {
-            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0};
+            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0.f, 0u};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         }
         flags = res.flags;
@@ -264,35 +266,10 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
     return true;
 }
 
-// remaining attempts of a rejection draw, from attempt `att` on (queue overflow only)
-__device__ __forceinline__ int32_t btrs_finish(const BtrsConsts C, const Rng g, uint32_t kind, uint32_t bin, uint32_t att)
-{
-    for (; att < BINOM_MAX_ATTEMPTS; att++) {
-        uint32_t wa, wb;
-        retry_pair(g, kind, bin, att, wa, wb);
-        const int32_t k = btrs_attempt(C, wa, wb);
-        if (k >= 0) return k;
-    }
-    return (int32_t)C.m;
-}
-
-__device__ __forceinline__ double gamma_finish_from(const GammaConsts G, double scale, const Rng g, uint32_t bin, uint32_t att)
-{
-    double v = 1.0;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    float z0 = 0.f, z1 = 0.f;
-    bool have = false;
-    for (; att < GAMMA_MAX_ATTEMPTS; att++) {
-        if (!have || (att & 1u) == 0u) { rng_block(g, K_GAMMA, bin, att >> 1, w); box_muller(w[0], w[1], z0, z1); have = true; }
-        double vv;
-        if (gamma_attempt(G, (att & 1u) ? z1 : z0, (att & 1u) ? w[3] : w[2], vv)) { v = vv; break; }
-    }
-    return gamma_finish(G, v, scale, g, bin);
-}
-
 template <bool WEIGH>
-__global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const epi_params P)
+__global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
+    const epi_params& P = Dp->P;
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = P.H, D = P.D;
     int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][TPB]: (I_i, tested_i) -> (sympt_i, pos_i)
@@ -364,7 +341,7 @@ __global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const ep
                 int32_t x; double pp; bool flip;
                 const int cls = binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
                 bool fail = false;
-                if (cls == BINOM_INVERSION) x = binom_inversion(n, pp, wa);
+                if (cls == BINOM_INVERSION) x = binom_inversion(n, Dp->lnq[j][i], Dp->sr[j][i], wa);
                 else if (cls == BINOM_REJECTION) {
                     const BtrsConsts C = btrs_consts(n, pp, screen);
                     x = btrs_attempt(C, wa, wb);
@@ -432,6 +409,8 @@ __global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const ep
     // iteration `it` handles bin (it == 0 ? H-1 : it-1), whose survivors seed infection term `it`
     // (the circular shift of simulate.jl:145)
     int32_t sum_inf = 0;
+    float z_odd = 0.f;              // second normal / word of the pair block, for the odd term
+    uint32_t w_odd = 0u;
 #pragma unroll 1
     for (int it = 0; it < H; it++) {
         const int i = it == 0 ? H - 1 : it - 1;
@@ -457,15 +436,20 @@ __global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const ep
             if (it == 0) R += Ii;                                                  // simulate.jl:144
             else { out[(int64_t)(2 + it) * os + m] = Ii; sum_inf += Ii; }          // simulate.jl:145
             const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78
+            float zf = z_odd;
+            uint32_t wu = w_odd;
+            if ((it & 1) == 0) {                                                   // an even term generates the block of its pair
+                uint32_t w[4];
+                float z0;
+                rng_block(g, K_GAMMA, (uint32_t)it >> 1, 0, w);
+                box_muller(w[0], w[1], z0, z_odd);
+                zf = z0; wu = w[2]; w_odd = w[3];
+            }
             if (gamma_is_zero(shape)) gslots[i * TPB + tid] = 0.0;
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
-                uint32_t w[4];
-                rng_block(g, K_GAMMA, (uint32_t)it, 0, w);
-                float z0, z1;
-                box_muller(w[0], w[1], z0, z1);
                 double v;
-                if (gamma_attempt(G, z0, w[2], v)) gslots[i * TPB + tid] = gamma_finish(G, v, P.theta[it], g, (uint32_t)it);
+                if (gamma_attempt(G, zf, wu, v)) gslots[i * TPB + tid] = gamma_finish(G, v, P.theta[it], g, (uint32_t)it);
                 else { slots[i * TPB + tid] = make_int2(Ii, 0); gfail = true; }
             }
         }
@@ -497,12 +481,10 @@ __global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const ep
                 const int32_t Ii = slots[i * TPB + t].x;
                 const GammaConsts G = gamma_consts(P.k[it] * (double)Ii, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
-                uint32_t w[4];
-                rng_block(gt, K_GAMMA, (uint32_t)it, round >> 1, w);
-                float z0, z1;
-                box_muller(w[0], w[1], z0, z1);
+                float zf; uint32_t wu;
+                gamma_retry(gt, (uint32_t)it, round, zf, wu);
                 double v;
-                const bool ok = gamma_attempt(G, (round & 1u) ? z1 : z0, (round & 1u) ? w[3] : w[2], v);
+                const bool ok = gamma_attempt(G, zf, wu, v);
                 const bool pushed = q_push(!ok, entry, qnext, &qn[cur ^ 1]);
                 if (ok) gslots[i * TPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
                 else if (!pushed) gslots[i * TPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
@@ -564,9 +546,9 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        k_step_coop<WEIGH><<<grid, blk, lds, c->stream>>>(A, c->P);
+        k_step_coop<WEIGH><<<grid, blk, lds, c->stream>>>(A, c->d_params);
     } else {
-        k_step<WEIGH, MODE_PHILOX><<<grid, blk, 0, c->stream>>>(A, c->P);
+        k_step<WEIGH, MODE_PHILOX><<<grid, blk, 0, c->stream>>>(A, c->d_params);
     }
     return hipGetLastError();
 }
@@ -801,7 +783,9 @@ __global__ __launch_bounds__(TPB) void k_sample_gamma(int64_t count, const doubl
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= count) return;
     Rng g = rng_make(seed, (uint64_t)j, step);
-    out[j] = gamma_draw(shape[j], scale[j], g, bin, screen);
+    float zf; uint32_t wu;
+    gamma_first(g, bin, zf, wu);
+    out[j] = gamma_draw(shape[j], scale[j], zf, wu, g, bin, screen);
 }
 
 // ---------------------------------------------------------------------------
@@ -902,6 +886,7 @@ int epi_ctx_create(int device, epi_ctx** out)
     HIPCHECK(hipStreamCreate(&c->stream));
     HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
     HIPCHECK(hipMemset(c->d_scal, 0, 256));
+    HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
     HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
     HIPCHECK(hipEventCreate(&c->ev0));
     HIPCHECK(hipEventCreate(&c->ev1));
@@ -918,6 +903,7 @@ int epi_ctx_destroy(epi_ctx* c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->d_sums) (void)hipFree(c->d_sums);
+    if (c->d_params) (void)hipFree(c->d_params);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return EPI_OK;
@@ -936,6 +922,13 @@ int epi_params_set(epi_ctx* c, const epi_params* p)
         if (!(p->p[i] >= 0.0 && p->p[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: p[%d] = %g not a probability", i, p->p[i]);
         if (!(p->k[i] >= 0.0) || !(p->theta[i] >= 0.0)) return fail(EPI_EINVAL, "epi_params_set: Gamma parameters of bin %d negative", i);
     }
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    DevParams dp;
+    memset(&dp, 0, sizeof dp);
+    dp.P = *p;
+    derive_params(dp);
+    HIPCHECK(hipMemcpy(c->d_params, &dp, sizeof dp, hipMemcpyHostToDevice));
     c->P = *p;
     c->have_params = true;
     return EPI_OK;
@@ -1242,7 +1235,7 @@ int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_part
     A.scal = c->d_scal; A.slot0 = (uint64_t)b->slot0;
     A.inj_sympt = ds.as<int32_t>(); A.inj_pos = dp.as<int32_t>(); A.inj_gam = dg.as<double>();
     A.newinf_out = dni.as<int32_t>(); A.pos_out = dpo.as<int32_t>();
-    k_step<false, MODE_INJECT><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+    k_step<false, MODE_INJECT><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
     HIPCHECK(hipGetLastError());
     if (new_inf_out) {
         std::vector<int32_t> h((size_t)n);
@@ -1285,7 +1278,7 @@ int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32
     A.a = a; A.a_row_stride = 1;
     A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
     A.rec_sympt = ds.as<int32_t>(); A.rec_pos = dp.as<int32_t>(); A.rec_gam = dg.as<double>();
-    k_step<false, MODE_RECORD><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->P);
+    k_step<false, MODE_RECORD><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
     HIPCHECK(hipGetLastError());
     std::vector<int32_t> hs(cnt), hp(cnt);
     std::vector<double> hg(cnt);

@@ -20,7 +20,8 @@ namespace epi {
 constexpr uint32_t K_BINOM0 = 0u;  // words 0,1: isolation draw attempt 0; words 2,3: positive-test draw attempt 0
 constexpr uint32_t K_SYMPT  = 1u;  // blk j: isolation attempts 1+2j (words 0,1) and 2+2j (words 2,3)
 constexpr uint32_t K_POS    = 2u;  // same for the positive-test draw
-constexpr uint32_t K_GAMMA  = 3u;  // blk j: attempts 2j (normal 0, word 2) and 2j+1 (normal 1, word 3)
+constexpr uint32_t K_GAMMA  = 3u;  // bin = pair j: attempt 0 of infection term 2j (normal 0, word 2) and of term 2j+1 (normal 1, word 3)
+constexpr uint32_t K_GRETRY = 7u;  // bin = term, blk b: its attempts 1+2b (normal 0, word 2) and 2+2b (normal 1, word 3)
 constexpr uint32_t K_BOOST  = 4u;  // word 0: uniform of the shape<1 boost
 constexpr uint32_t K_RESAMP = 5u;  // slot 0: words 0,1 -> 53-bit systematic-resampling offset
 constexpr uint32_t K_INIT   = 6u;  // initial-state generators
@@ -273,20 +274,49 @@ EPI_HD int binom_classify(int32_t n, double p, int32_t& result, double& pp, bool
     return ((double)n * pp < 10.0) ? BINOM_INVERSION : BINOM_REJECTION;
 }
 
-EPI_HD int32_t binom_inversion(int32_t n, double pp, uint32_t wa)
+// 1/x for the inversion recurrence (x <= 64; beyond that a division)
+#define EPI_R(x) (1.0 / (double)(x))
+#define EPI_R8(b) EPI_R(b), EPI_R(b + 1), EPI_R(b + 2), EPI_R(b + 3), EPI_R(b + 4), EPI_R(b + 5), EPI_R(b + 6), EPI_R(b + 7)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#else
+static
+#endif
+const double EPI_RECIP[72] = { 0.0, EPI_R(1), EPI_R(2), EPI_R(3), EPI_R(4), EPI_R(5), EPI_R(6), EPI_R(7),
+    EPI_R8(8), EPI_R8(16), EPI_R8(24), EPI_R8(32), EPI_R8(40), EPI_R8(48), EPI_R8(56), EPI_R8(64) };
+
+// lnq = s_log(1 - pp), s = pp / (1 - pp): per-probability constants, tabulated per age bin by the kernels
+EPI_HD int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
 {
-    const double nd = (double)n, qq = 1.0 - pp;
-    const double s = pp / qq;
-    const double a = (nd + 1.0) * s;
-    double r = s_exp(nd * s_log(qq));
+    const double nd = (double)n;
+    const double a1 = nd + 1.0;
+    double r = s_exp(nd * lnq);
     double u = u01(wa);
-    int32_t x = 0;
-    while (u > r && x < n) {
-        u -= r;
-        x += 1;
-        r *= (a / (double)x - s);
+    int32_t res = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the same recurrence with a wave-uniform counter, so that 1/x is a scalar table read
+    bool live = u > r && 0 < n;
+#pragma unroll 1
+    for (int32_t x = 1; __any(live); x++) {
+        const double xd = (double)x;
+        const double t = x <= 64 ? EPI_RECIP[x] : 1.0 / xd;
+        if (live) {
+            u -= r;
+            res = x;
+            r *= s * ((a1 - xd) * t);
+            live = u > r && x < n;
+        }
     }
-    return x;
+#else
+    while (u > r && res < n) {
+        u -= r;
+        res += 1;
+        const double xd = (double)res;
+        const double t = res <= 64 ? EPI_RECIP[res] : 1.0 / xd;
+        r *= s * ((a1 - xd) * t);
+    }
+#endif
+    return res;
 }
 
 struct BtrsConsts {
@@ -386,6 +416,21 @@ EPI_HD void retry_pair(const Rng& g, uint32_t retry_kind, uint32_t bin, uint32_t
     wb = half ? w[3] : w[1];
 }
 
+// remaining attempts of a rejection draw, from attempt `att` (>= 1) on
+EPI_HD int32_t btrs_finish(const BtrsConsts& C, const Rng& g, uint32_t kind, uint32_t bin, uint32_t att)
+{
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    bool have = false;
+#pragma unroll 1
+    for (; att < BINOM_MAX_ATTEMPTS; att++) {
+        const bool half = ((att - 1u) & 1u) != 0u;
+        if (!have || !half) { rng_block(g, kind, bin, (att - 1u) >> 1, w); have = true; }
+        const int32_t k = btrs_attempt(C, half ? w[2] : w[0], half ? w[3] : w[1]);
+        if (k >= 0) return k;
+    }
+    return (int32_t)C.m;                     // only if every attempt fails
+}
+
 // fa, fb: the attempt-0 word pair; attempts a >= 1 come from blocks of retry_kind.
 // screen: allow the binary32 screens (device only; never changes the result).
 EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
@@ -394,20 +439,11 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
     int32_t x; double pp; bool flip;
     const int cls = binom_classify(n, p, x, pp, flip);
     if (cls == BINOM_DONE) return x;
-    if (cls == BINOM_INVERSION) x = binom_inversion(n, pp, fa);
+    if (cls == BINOM_INVERSION) x = binom_inversion(n, s_log(1.0 - pp), pp / (1.0 - pp), fa);
     else {
         const BtrsConsts C = btrs_consts(n, pp, screen);
-        x = (int32_t)C.m;                    // returned only if every attempt fails
-        uint32_t w[4] = {0u, 0u, fa, fb};
-        // attempt j-1 takes words (2,3) of its block when j is odd and words (0,1) when j is even;
-        // the attempt-0 pair sits in words (2,3) of the initial contents
-#pragma unroll 1
-        for (uint32_t j = 1; j <= BINOM_MAX_ATTEMPTS; j++) {
-            const uint32_t half = j & 1u;
-            if (half == 0u) rng_block(g, retry_kind, bin, (j - 2u) >> 1, w);
-            const int32_t k = btrs_attempt(C, half ? w[2] : w[0], half ? w[3] : w[1]);
-            if (k >= 0) { x = k; break; }
-        }
+        x = btrs_attempt(C, fa, fb);
+        if (x < 0) x = btrs_finish(C, g, retry_kind, bin, 1u);
     }
     return flip ? n - x : x;
 }
@@ -490,23 +526,53 @@ EPI_HD double gamma_finish(const GammaConsts& G, double v, double scale, const R
     return gval * scale;
 }
 
-EPI_HD double gamma_draw(double shape, double scale, const Rng& g, uint32_t bin, bool screen = true)
+// attempt-0 normal and word of infection term `bin` (shared block of the pair bin/2)
+EPI_HD void gamma_first(const Rng& g, uint32_t bin, float& zf, uint32_t& wu)
+{
+    uint32_t w[4];
+    float z0, z1;
+    rng_block(g, K_GAMMA, bin >> 1, 0, w);
+    box_muller(w[0], w[1], z0, z1);
+    zf = (bin & 1u) ? z1 : z0;
+    wu = (bin & 1u) ? w[3] : w[2];
+}
+
+// normal and word of attempt att >= 1
+EPI_HD void gamma_retry(const Rng& g, uint32_t bin, uint32_t att, float& zf, uint32_t& wu)
+{
+    uint32_t w[4];
+    float z0, z1;
+    rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w);
+    box_muller(w[0], w[1], z0, z1);
+    const bool half = ((att - 1u) & 1u) != 0u;
+    zf = half ? z1 : z0;
+    wu = half ? w[3] : w[2];
+}
+
+// remaining attempts of a gamma draw from attempt `att` (>= 1) on, then boost and scale
+EPI_HD double gamma_finish_from(const GammaConsts& G, double scale, const Rng& g, uint32_t bin, uint32_t att)
+{
+    double v = 1.0, vv;                        // v = 1 only if every attempt fails
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    float z0 = 0.f, z1 = 0.f;
+    bool have = false;
+#pragma unroll 1
+    for (; att < GAMMA_MAX_ATTEMPTS; att++) {
+        const bool half = ((att - 1u) & 1u) != 0u;
+        if (!have || !half) { rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w); box_muller(w[0], w[1], z0, z1); have = true; }
+        if (gamma_attempt(G, half ? z1 : z0, half ? w[3] : w[2], vv)) { v = vv; break; }
+    }
+    return gamma_finish(G, v, scale, g, bin);
+}
+
+// zf, wu: the attempt-0 normal and word (gamma_first)
+EPI_HD double gamma_draw(double shape, double scale, float zf, uint32_t wu, const Rng& g, uint32_t bin, bool screen = true)
 {
     if (gamma_is_zero(shape)) return 0.0;
     const GammaConsts G = gamma_consts(shape, screen);
-    double v = 1.0;                            // used only if every attempt fails
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    float z0 = 0.f, z1 = 0.f;
-#pragma unroll 1
-    for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
-        if ((att & 1u) == 0u) {
-            rng_block(g, K_GAMMA, bin, att >> 1, w);
-            box_muller(w[0], w[1], z0, z1);
-        }
-        double vv;
-        if (gamma_attempt(G, (att & 1u) ? z1 : z0, (att & 1u) ? w[3] : w[2], vv)) { v = vv; break; }
-    }
-    return gamma_finish(G, v, scale, g, bin);
+    double vv;
+    if (gamma_attempt(G, zf, wu, vv)) return gamma_finish(G, vv, scale, g, bin);
+    return gamma_finish_from(G, scale, g, bin, 1u);
 }
 
 // 53-bit uniform in [0,1) of the systematic resampler for (seed, step)

@@ -34,11 +34,50 @@ namespace epi {
 __host__ __device__ __forceinline__ int state_rows(int H, int D) { return 2 + H + D * (H - 1); }
 __host__ __device__ __forceinline__ int tests_row(int H, int r0, int c0) { return 2 + H + r0 * (H - 1) + (c0 - 1); }  // r0 in [0,D), c0 in [1,H)
 
+// Parameters as the kernels read them (device memory): the caller's struct plus constants that
+// depend on the probabilities only, for both binomial draws of a bin (0: isolation, 1: positive test).
+struct DevParams {
+    epi_params P;
+    double lnq[2][EPI_MAX_H];   // s_log(1 - pp), pp = min(p, 1 - p)
+    double sr[2][EPI_MAX_H];    // pp / (1 - pp)
+};
+
+__host__ __device__ inline void derive_params(DevParams& D)
+{
+    for (int j = 0; j < 2; j++)
+        for (int i = 0; i < EPI_MAX_H; i++) {
+            const double p = i < D.P.H ? (j ? D.P.p[i] : D.P.q[i]) : 0.0;
+            const double pp = p > 0.5 ? 1.0 - p : p;
+            const bool ok = pp > 0.0 && pp < 1.0;
+            D.lnq[j][i] = ok ? s_log(1.0 - pp) : 0.0;
+            D.sr[j][i] = ok ? pp / (1.0 - pp) : 0.0;
+        }
+}
+
+// One binomial draw of a bin (j = 0 isolation, 1 positive test) from its attempt-0 word pair.
+__device__ __forceinline__ int32_t bin_binomial(const DevParams& D, int bin, int j, int32_t n, uint32_t fa, uint32_t fb,
+                                                const Rng& g, bool screen)
+{
+    int32_t x; double pp; bool flip;
+    const int cls = binom_classify(n, j ? D.P.p[bin] : D.P.q[bin], x, pp, flip);
+    if (cls == BINOM_DONE) return x;
+    if (cls == BINOM_INVERSION) x = binom_inversion(n, D.lnq[j][bin], D.sr[j][bin], fa);
+    else {
+        const BtrsConsts C = btrs_consts(n, pp, screen);
+        x = btrs_attempt(C, fa, fb);
+        if (x < 0) x = btrs_finish(C, g, j ? K_POS : K_SYMPT, (uint32_t)bin, 1u);
+    }
+    return flip ? n - x : x;
+}
+
 // Variates from the Philox streams of one (slot, step).
 struct PhiloxDraws {
     Rng g;
     bool screen;    // allow the binary32 screens of the rejection samplers (results do not depend on it)
-    __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double q, int32_t n_tested, double p,
+    const DevParams* D;
+    mutable float z_odd;        // second normal / word of the last gamma pair block
+    mutable uint32_t w_odd;
+    __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double, int32_t n_tested, double,
                                                int32_t& sympt, int32_t& pos) const
     {
         uint32_t w[4];
@@ -46,32 +85,39 @@ struct PhiloxDraws {
         // one instance of the sampler code for both draws
 #pragma unroll 1
         for (int j = 0; j < 2; j++) {
-            const int32_t r = binomial_draw(j ? n_tested : n_inf, j ? p : q, j ? w[2] : w[0], j ? w[3] : w[1],
-                                            g, j ? K_POS : K_SYMPT, (uint32_t)bin, screen);
+            const int32_t r = bin_binomial(*D, bin, j, j ? n_tested : n_inf, j ? w[2] : w[0], j ? w[3] : w[1], g, screen);
             if (j) pos = r; else sympt = r;
         }
     }
+    // infection terms are drawn in order 0, 1, 2, ...: an even term generates the block of its pair
     __device__ __forceinline__ double gamma(int bin, double shape, double scale) const
     {
-        return gamma_draw(shape, scale, g, (uint32_t)bin, screen);
+        float zf; uint32_t wu;
+        if ((bin & 1) == 0) {
+            uint32_t w[4];
+            float z0, z1;
+            rng_block(g, K_GAMMA, (uint32_t)bin >> 1, 0, w);
+            box_muller(w[0], w[1], z0, z1);
+            zf = z0; wu = w[2]; z_odd = z1; w_odd = w[3];
+        } else { zf = z_odd; wu = w_odd; }
+        return gamma_draw(shape, scale, zf, wu, g, (uint32_t)bin, screen);
     }
 };
 
 // Philox variates that are also written out (rows of n elements per age bin),
 // so that another implementation of the step can be driven by the same draws.
 struct RecordingDraws {
-    Rng g; int32_t* sympt; int32_t* pos; double* gam; int64_t n; int64_t idx;
+    PhiloxDraws d; int32_t* sympt; int32_t* pos; double* gam; int64_t n; int64_t idx;
     __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double q, int32_t n_tested, double p,
                                                int32_t& s, int32_t& ps) const
     {
-        PhiloxDraws d{g, true};
         d.binomials(bin, n_inf, q, n_tested, p, s, ps);
         sympt[(int64_t)bin * n + idx] = s;
         pos[(int64_t)bin * n + idx] = ps;
     }
     __device__ __forceinline__ double gamma(int bin, double shape, double scale) const
     {
-        double v = gamma_draw(shape, scale, g, (uint32_t)bin);
+        double v = d.gamma(bin, shape, scale);
         gam[(int64_t)bin * n + idx] = v;
         return v;
     }

@@ -113,7 +113,8 @@ void orc_philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out[4]
 #define K_BINOM0  0u  /* words 0,1: sympt attempt 0 ; words 2,3: pos attempt 0      */
 #define K_SYMPT   1u  /* blk j: sympt attempts 1+2j (words 0,1) and 2+2j (words 2,3) */
 #define K_POS     2u  /* same for pos                                              */
-#define K_GAMMA   3u  /* blk j: attempts 2j (z0, word 2) and 2j+1 (z1, word 3)      */
+#define K_GAMMA   3u  /* bin = pair j: attempt 0 of infection term 2j (z0, word 2), of term 2j+1 (z1, word 3) */
+#define K_GRETRY  7u  /* bin = term, blk b: its attempts 1+2b (z0, word 2) and 2+2b (z1, word 3) */
 #define K_BOOST   4u  /* word 0: U for the shape<1 boost                            */
 #define K_RESAMP  5u  /* particle = 0: words 0,1 -> 53-bit systematic offset        */
 #define K_INIT    6u  /* initial-state generators                                  */
@@ -277,6 +278,12 @@ static void binom_pair(binom_src *s, uint32_t attempt, uint32_t *wa, uint32_t *w
 
 #define BINOM_MAX_ATTEMPTS 512u
 
+static double recip_tab[65];
+__attribute__((constructor)) static void recip_init(void)
+{
+    for (int x = 1; x <= 64; x++) recip_tab[x] = 1.0 / (double)x;
+}
+
 static int64_t binomial_draw(int64_t n, double p, binom_src *src)
 {
     if (n <= 0 || !(p > 0.0)) return 0;
@@ -289,15 +296,18 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
     if (nd * pp < 10.0) {
         uint32_t wa, wb;
         binom_pair(src, 0, &wa, &wb);
+        /* sequential inversion: pmf(x) = pmf(x-1) s (n+1-x)/x, with 1/x tabulated up to 64 */
         double s = pp / qq;
-        double a = (nd + 1.0) * s;
+        double a1 = nd + 1.0;
         double r = s_exp(nd * s_log(qq));
         double u = u01(wa);
         x = 0;
         while (u > r && x < n) {
             u -= r;
             x += 1;
-            r *= (a / (double)x - s);
+            double xd = (double)x;
+            double t = x <= 64 ? recip_tab[x] : 1.0 / xd;
+            r *= s * ((a1 - xd) * t);
         }
     } else {
         /* hat parameters: sqrt and 1/b in binary32 (Hoermann's constants carry 3 digits) */
@@ -350,11 +360,15 @@ static double gamma_draw(double shape, double scale, const rng_t *g, uint32_t bi
     double v = 1.0;
     uint32_t w[4];
     for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
-        if ((att & 1u) == 0) rng_block(g, K_GAMMA, bin, att >> 1, w);
+        /* attempt 0 shares the block of the pair bin/2 (half bin&1); attempt a >= 1 takes half (a-1)&1 of
+         * block (a-1)/2 of the term's own retry stream */
+        uint32_t half = att == 0 ? (bin & 1u) : ((att - 1u) & 1u);
+        if (att == 0) rng_block(g, K_GAMMA, bin >> 1, 0, w);
+        else rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w);
         float z0, z1;
         box_muller(w[0], w[1], &z0, &z1);
-        double x = (double)((att & 1u) ? z1 : z0);
-        double u = u01((att & 1u) ? w[3] : w[2]);
+        double x = (double)(half ? z1 : z0);
+        double u = u01(half ? w[3] : w[2]);
         double t = 1.0 + c * x;
         if (!(t > 0.0)) continue;
         double vv = t * t * t;

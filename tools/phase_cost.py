@@ -33,6 +33,6 @@ variants = [
     ("no test draws (p=0)", em.make_pomdp(pos_test_probs=[0.0] * 14)),
     ("neither", em.make_pomdp(symptomatic_isolation_prob=0.0, pos_test_probs=[0.0] * 14, Infdistributions=zero_g)),
 ]
-for impl in (1, 0):
+for impl in ([int(sys.argv[1])] if len(sys.argv) > 1 else (1, 0)):
     for name, p in variants:
         run(name, p, impl=impl)

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_gamma(uint64_t seed, const double* sh, 
     if (i >= n) return;
     Rng g = rng_make(seed, i, 0);
     double acc = 0, s = sh[i];
-    for (int r = 0; r < REP; r++) acc += gamma_draw(s, 0.1, g, r);
+    for (int r = 0; r < REP; r++) { float zf; uint32_t wu; gamma_first(g, r, zf, wu); acc += gamma_draw(s, 0.1, zf, wu, g, r); }
     out[i] = acc;
 }
 __global__ __launch_bounds__(256) void k_log(const double* x, double* out, int64_t n)
