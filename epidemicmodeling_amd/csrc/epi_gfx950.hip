@@ -267,7 +267,7 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 }
 
 template <bool WEIGH>
-__global__ __launch_bounds__(TPB, 4) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
+__global__ __launch_bounds__(TPB, 3) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
     extern __shared__ __align__(16) unsigned char smem[];
