@@ -98,6 +98,13 @@ def run_single(args):
     ksum, kcnt = C.c_double(), C.c_int64()
     check(lib.epi_ctx_timing_read(ctx.handle, C.byref(ksum), C.byref(kcnt)))
     check(lib.epi_ctx_timing(ctx.handle, 0))
+    if args.calibrate:
+        # one dispatch of the plain gather kernel (reads ancestor index + every row, writes every row: the step
+        # kernel's own access pattern with a known byte count) for calibrating the memory-side PMC counters
+        b2 = em.initialbelief(pomdp, n, seed=SEED + 1)
+        check(lib.epi_belief_copy(b2.handle, b.handle))
+        torch.cuda.synchronize()
+        b2.close()
     return pomdp, n, dt, ksum.value / max(kcnt.value, 1), dict(loglik=ll.value, ess=ess.value, flags=fl.value)
 
 
@@ -145,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="after the timed region, run one gather dispatch of known traffic (PMC calibration)")
     args = ap.parse_args()
 
     rank = 0

@@ -1097,11 +1097,17 @@ int epi_belief_copy(epi_belief* dst, epi_belief* src)
         return fail(EPI_EINVAL, "epi_belief_copy: beliefs differ in shape or context");
     epi_ctx* c = src->ctx;
     HIPCHECK(hipSetDevice(c->device));
-    size_t bytes = sizeof(int32_t) * (size_t)src->rows * (size_t)src->stride;
-    HIPCHECK(hipMemcpyAsync(dst->buf[dst->cur], src->buf[src->cur], bytes, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(dst->anc, src->anc, sizeof(int32_t) * (size_t)src->n, hipMemcpyDeviceToDevice, c->stream));
+    if (src->has_anc) {
+        // the copy resolves the source's pending ancestor indirection on the way (one gather pass, source untouched)
+        k_gather<<<dim3((unsigned)ceil_div(src->n, TPB)), dim3(TPB), 0, c->stream>>>(src->n, src->buf[src->cur], src->stride, src->anc,
+                                                                                   dst->buf[dst->cur], src->rows);
+        HIPCHECK(hipGetLastError());
+    } else {
+        size_t bytes = sizeof(int32_t) * (size_t)src->rows * (size_t)src->stride;
+        HIPCHECK(hipMemcpyAsync(dst->buf[dst->cur], src->buf[src->cur], bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIPCHECK(hipStreamSynchronize(c->stream));
-    dst->has_anc = src->has_anc; dst->n_total = src->n_total; dst->slot0 = src->slot0; dst->phase = PH_IDLE;
+    dst->has_anc = false; dst->n_total = src->n_total; dst->slot0 = src->slot0; dst->phase = PH_IDLE;
     return EPI_OK;
 }
 
