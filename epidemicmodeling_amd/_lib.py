@@ -18,7 +18,8 @@ EPI_F_BAD_DENOM = 4
 EPI_F_ZERO_W = 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libepi_gfx950.so")
+# EPI_GFX950_LIB points at another build of the same library (kernel A/B measurements); there is still no fallback.
+LIB_PATH = os.environ.get("EPI_GFX950_LIB") or os.path.join(_HERE, "csrc", "libepi_gfx950.so")
 
 
 class EpiLibraryError(RuntimeError):
