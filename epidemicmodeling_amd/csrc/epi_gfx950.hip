@@ -266,8 +266,35 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
     return true;
 }
 
+// the same for up to two entries per lane (entry e0 if want0, e1 if want1) with one atomic per wave;
+// ok0 / ok1 = false where the entry did not fit
+__device__ __forceinline__ void q_push2(bool want0, bool want1, unsigned short e0, unsigned short e1, unsigned short* q, unsigned int* qn,
+                                        bool& ok0, bool& ok1)
+{
+    ok0 = true; ok1 = true;
+    const unsigned long long m0 = __ballot(want0), m1 = __ballot(want1);
+    if ((m0 | m1) == 0ULL) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned int c0 = (unsigned int)__popcll(m0), c1 = (unsigned int)__popcll(m1);
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(qn, c0 + c1);
+    base = __shfl(base, 0, 64);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    if (want0) {
+        const unsigned int pos = base + (unsigned int)__popcll(m0 & below);
+        if (pos < QCAP) q[pos] = e0; else ok0 = false;
+    }
+    if (want1) {
+        const unsigned int pos = base + c0 + (unsigned int)__popcll(m1 & below);
+        if (pos < QCAP) q[pos] = e1; else ok1 = false;
+    }
+}
+
+#ifndef EPI_COOP_WAVES
+#define EPI_COOP_WAVES 3   // waves per SIMD the register allocation aims at: 168 VGPRs; 4 spills, 2 starves the issue slots
+#endif
 template <bool WEIGH>
-__global__ __launch_bounds__(TPB, 3) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
+__global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -353,8 +380,8 @@ __global__ __launch_bounds__(TPB, 3) void k_step_coop(const StepArgs A, const De
             slots[i * TPB + tid] = nn;
         }
         const unsigned short e0 = (unsigned short)(tid | (i << 8));
-        const bool ok0 = q_push(fail0, e0, q0, &qn[0]);
-        const bool ok1 = q_push(fail1, (unsigned short)(e0 | (1 << 14)), q0, &qn[0]);
+        bool ok0, ok1;
+        q_push2(fail0, fail1, e0, (unsigned short)(e0 | (1 << 14)), q0, &qn[0], ok0, ok1);
         if ((fail0 && !ok0) || (fail1 && !ok1)) {                                  // queue full: finish here
             int2 nn = slots[i * TPB + tid];
             for (int j = 0; j < 2; j++) {

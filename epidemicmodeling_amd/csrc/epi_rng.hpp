@@ -239,8 +239,10 @@ __device__ __forceinline__ float f_stirling_tail(float kp1)
 
 // The defining acceptance test of the transformed-rejection sampler (Hoermann 1993, step 3):
 // log(v alpha / (a/us^2 + b)) <= log f(k) - log f(m), with Stirling-corrected log factorials.
+// (out of line on the device: it runs for a few draws in ten thousand, and inlined its four logarithms set the
+// register allocation of every kernel that samples a binomial)
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__
+__device__ __noinline__
 #else
 static inline
 #endif
@@ -254,6 +256,19 @@ bool btrs_accept_exact(double nd, double pp, double qq, double m, double kd, dou
                     + stirling_tail(m) + stirling_tail(nd - m)
                     - stirling_tail(kd) - stirling_tail(nd - kd);
     return lv <= ub;
+}
+
+// lv - ub of the same test in binary64 (measurement of the screens' error only)
+EPI_HD double btrs_exact_diff(double nd, double pp, double qq, double m, double kd, double v, double us, double a, double b, double alpha)
+{
+    const double r = pp / qq;
+    const double lv = s_log(v * alpha / (a / (us * us) + b));
+    const double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
+                    + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
+                    + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
+                    + stirling_tail(m) + stirling_tail(nd - m)
+                    - stirling_tail(kd) - stirling_tail(nd - kd);
+    return lv - ub;
 }
 
 // A Binomial(n, p) draw is split into pieces so that a kernel can either loop over attempts
@@ -363,12 +378,31 @@ EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, bool screen)
     return C;
 }
 
-// one attempt: returns the accepted k (>= 0) or -1
-EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
+#ifdef EPI_HAVE_SCREEN
+// binary32 estimate of lv - ub of the acceptance test (accept iff lv <= ub) and the sum `mag` of the magnitudes
+// of its terms.  Rounding analysis (unit roundoff 6e-8, rcp / log2 within 1 ulp, Stirling tails within 3e-7):
+// |estimate - exact| < 1.5e-6 mag + 2e-6.  Measured over 2e9 undecided attempts (n from 20 to 1.6e7, p from 3e-6
+// to 0.9999; tools/ubench.hip): never above 3e-6 mag + 1e-5.  The guard band is four times the measured worst case.
+constexpr float BTRS_GUARD_REL = 1.2e-5f, BTRS_GUARD_ABS = 4e-5f;
+__device__ __forceinline__ float btrs_screen(const BtrsConsts& C, double kd, double us, double v, float& mag)
 {
-    const double u = u01(wa) - 0.5;
-    const double v = u01(wb);
-    const double us = 0.5 - __builtin_fabs(u);
+    const float dk = (float)(kd - C.m);
+    const float k1f = C.m1f + dk, nk1f = C.n1f - dk;
+    const float usf = (float)us;
+    const float lv = f_ln((float)v * C.alf * f_rcp(__builtin_fmaf(C.af, f_rcp(usf * usf), C.bf)));
+    const float t_a = dk * C.LA;
+    const float t_l1 = dk * (dk + 0.5f) * C.rn1, t_l2 = dk * (dk - 0.5f) * C.rm1;
+    const float t_g1 = (nk1f - 0.5f) * f_log1p_minus(-dk * C.rn1), t_g2 = (k1f - 0.5f) * f_log1p_minus(dk * C.rm1);
+    const float t_fc = f_stirling_tail(k1f) + f_stirling_tail(nk1f);
+    const float ub = C.fcm - t_fc - t_a - t_l1 - t_l2 - t_g1 - t_g2;
+    mag = __builtin_fabsf(lv) + __builtin_fabsf(t_a) + t_l1 + t_l2 - t_g1 - t_g2 + C.fcm + t_fc;
+    return lv - ub;
+}
+#endif
+
+// k = floor((2a/us + b) u + c) of one attempt
+EPI_HD double btrs_k(const BtrsConsts& C, double u, double us)
+{
     double kd = 0.0;
     bool have_k = false;
 #ifdef EPI_HAVE_SCREEN
@@ -383,22 +417,23 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
     }
 #endif
     if (!have_k) kd = __builtin_floor((2.0 * C.a / us + C.b) * u + C.c);
+    return kd;
+}
+
+// one attempt: returns the accepted k (>= 0) or -1
+EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
+{
+    const double u = u01(wa) - 0.5;
+    const double v = u01(wb);
+    const double us = 0.5 - __builtin_fabs(u);
+    const double kd = btrs_k(C, u, us);
     if (kd < 0.0 || kd > C.nd) return -1;
     if (us >= 0.07 && v <= C.vr) return (int32_t)kd;
 #ifdef EPI_HAVE_SCREEN
     if (C.scr && kd >= 2.0 && C.nd - kd >= 2.0) {
-        const float dk = (float)(kd - C.m);
-        const float k1f = C.m1f + dk, nk1f = C.n1f - dk;
-        const float usf = (float)us;
-        const float lv = f_ln((float)v * C.alf * f_rcp(__builtin_fmaf(C.af, f_rcp(usf * usf), C.bf)));
-        const float t_a = dk * C.LA;
-        const float t_l1 = dk * (dk + 0.5f) * C.rn1, t_l2 = dk * (dk - 0.5f) * C.rm1;
-        const float t_g1 = (nk1f - 0.5f) * f_log1p_minus(-dk * C.rn1), t_g2 = (k1f - 0.5f) * f_log1p_minus(dk * C.rm1);
-        const float t_fc = f_stirling_tail(k1f) + f_stirling_tail(nk1f);
-        const float ub = C.fcm - t_fc - t_a - t_l1 - t_l2 - t_g1 - t_g2;
-        const float mag = __builtin_fabsf(lv) + __builtin_fabsf(t_a) + t_l1 + t_l2 - t_g1 - t_g2 + C.fcm + t_fc;
-        const float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
-        const float diff = lv - ub;
+        float mag;
+        const float diff = btrs_screen(C, kd, us, v, mag);
+        const float guard = __builtin_fmaf(mag, BTRS_GUARD_REL, BTRS_GUARD_ABS);
         if (diff < -guard) return (int32_t)kd;
         if (diff > guard) return -1;
     }
@@ -474,6 +509,33 @@ EPI_HD GammaConsts gamma_consts(double shape, bool screen)
     return G;
 }
 
+#ifdef EPI_HAVE_SCREEN
+// binary32 estimate of log u - [x^2/2 + d (1 - v + log v)] (accept iff < 0) for t = c x > -0.9, and the sum
+// `mag` of the magnitudes of its terms; estimate error < 1.5e-6 mag + 1e-6 by the same rounding analysis
+// (measured over 2e8 undecided attempts, shapes 1 to 1e8: never above 2e-7 mag + 5e-6).
+constexpr float GAMMA_GUARD_REL = 5e-6f, GAMMA_GUARD_ABS = 1e-4f;
+__device__ __forceinline__ float gamma_screen(float tf, float df, float uf, float& mag)
+{
+    const float t2 = tf * tf;
+    float q = 0.1f;
+    q = __builtin_fmaf(q, tf, -0.111111111f);
+    q = __builtin_fmaf(q, tf, 0.125f);
+    q = __builtin_fmaf(q, tf, -0.142857143f);
+    q = __builtin_fmaf(q, tf, 0.166666667f);
+    q = __builtin_fmaf(q, tf, -0.2f);
+    q = __builtin_fmaf(q, tf, 0.25f);
+    const float ser = -(t2 * t2) * q;                                 // log1p(t) - t + t^2/2 - t^3/3
+    const float l1p = f_ln(1.0f + tf);
+    const float big = l1p - tf + 0.5f * t2 - 0.333333333f * t2 * tf;
+    const float magb = __builtin_fabsf(l1p) + __builtin_fabsf(tf) + 0.5f * t2 + 0.333333333f * __builtin_fabsf(t2 * tf);
+    const bool small = __builtin_fabsf(tf) <= 0.125f;
+    const float rhs = 3.0f * df * (small ? ser : big);
+    const float lu = f_ln(uf);
+    mag = __builtin_fabsf(lu) + 3.0f * df * (small ? __builtin_fabsf(ser) : magb);
+    return lu - rhs;
+}
+#endif
+
 EPI_HD bool gamma_attempt(const GammaConsts& G, float xf, uint32_t wu, double& v)
 {
     const double x = (double)xf;
@@ -487,26 +549,11 @@ EPI_HD bool gamma_attempt(const GammaConsts& G, float xf, uint32_t wu, double& v
 #ifdef EPI_HAVE_SCREEN
     if (G.screen) {
         // x^2/2 + d (1 - v + log v) = 3 d (log1p(t) - t + t^2/2 - t^3/3), t = c x  (since 9 d c^2 = 1)
-        const float tf = (float)G.c * xf, df = (float)G.d;
+        const float tf = (float)G.c * xf;
         if (tf > -0.9f) {
-            const float t2 = tf * tf;
-            float q = 0.1f;
-            q = __builtin_fmaf(q, tf, -0.111111111f);
-            q = __builtin_fmaf(q, tf, 0.125f);
-            q = __builtin_fmaf(q, tf, -0.142857143f);
-            q = __builtin_fmaf(q, tf, 0.166666667f);
-            q = __builtin_fmaf(q, tf, -0.2f);
-            q = __builtin_fmaf(q, tf, 0.25f);
-            const float ser = -(t2 * t2) * q;                                 // log1p(t) - t + t^2/2 - t^3/3
-            const float l1p = f_ln(1.0f + tf);
-            const float big = l1p - tf + 0.5f * t2 - 0.333333333f * t2 * tf;
-            const float magb = __builtin_fabsf(l1p) + __builtin_fabsf(tf) + 0.5f * t2 + 0.333333333f * __builtin_fabsf(t2 * tf);
-            const bool small = __builtin_fabsf(tf) <= 0.125f;
-            const float rhs = 3.0f * df * (small ? ser : big);
-            const float lu = f_ln((float)u);
-            const float mag = __builtin_fabsf(lu) + 3.0f * df * (small ? __builtin_fabsf(ser) : magb);
-            const float guard = __builtin_fmaf(mag, 2e-5f, 5e-4f);
-            const float diff = lu - rhs;
+            float mag;
+            const float diff = gamma_screen(tf, (float)G.d, (float)u, mag);
+            const float guard = __builtin_fmaf(mag, GAMMA_GUARD_REL, GAMMA_GUARD_ABS);
             if (diff < -guard) return true;
             if (diff > guard) return false;
         }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include "../epidemicmodeling_amd/csrc/epi_rng.hpp"
 using namespace epi;
@@ -68,6 +69,115 @@ __global__ __launch_bounds__(256) void k_div(const double* x, double* out, int64
     out[i] = acc;
 }
 
+// issue rate of single instructions: 8 independent dependency chains per lane, OPS_REP rounds
+constexpr int OPS_REP = 256;
+enum { OP_FMA64, OP_FMA32, OP_PKFMA32, OP_MAD64, OP_MULLO, OP_MULHI, OP_XOR, OP_RCP32, OP_SQRT32, OP_LOG32, OP_RCP64, OP_CVT_F64_U32,
+       OP_CVT_F32_F64, OP_FLOOR64, OP_MUL64, OP_ADD64, OP_LDEXP64, OP_CNDMASK };
+template <int OP>
+__global__ __launch_bounds__(256) void k_ops(const double* x, double* out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double d[8]; float f[8]; uint32_t u[8]; uint64_t q[8];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p[8];
+    for (int c = 0; c < 8; c++) { d[c] = x[i] + c; f[c] = (float)d[c]; u[c] = (uint32_t)(i * 2654435761u) + c; q[c] = u[c]; p[c] = f2{f[c], f[c] + 1.f}; }
+#pragma unroll 1
+    for (int r = 0; r < OPS_REP; r++) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if constexpr (OP == OP_FMA64) d[c] = __builtin_fma(d[c], 1.0000001, 0.5);
+            else if constexpr (OP == OP_MUL64) d[c] = d[c] * 1.0000001;
+            else if constexpr (OP == OP_ADD64) d[c] = d[c] + 1.0000001;
+            else if constexpr (OP == OP_FMA32) f[c] = __builtin_fmaf(f[c], 1.0000001f, 0.5f);
+            else if constexpr (OP == OP_PKFMA32) p[c] = __builtin_elementwise_fma(p[c], f2{1.0000001f, 0.999999f}, f2{0.5f, 0.25f});
+            else if constexpr (OP == OP_MAD64) q[c] = (uint64_t)(uint32_t)q[c] * 0xD2511F53u + (q[c] >> 32);
+            else if constexpr (OP == OP_MULLO) u[c] = u[c] * 0xD2511F53u + 1u;
+            else if constexpr (OP == OP_MULHI) u[c] = __umulhi(u[c], 0xD2511F53u) + 12345u;
+            else if constexpr (OP == OP_XOR) u[c] = (u[c] ^ 0x9E3779B9u) + (u[c] >> 3);
+            else if constexpr (OP == OP_RCP32) f[c] = __builtin_amdgcn_rcpf(f[c]) + 1.0f;
+            else if constexpr (OP == OP_SQRT32) f[c] = __builtin_amdgcn_sqrtf(f[c]) + 2.0f;
+            else if constexpr (OP == OP_LOG32) f[c] = __builtin_amdgcn_logf(f[c]) + 3.0f;
+            else if constexpr (OP == OP_RCP64) d[c] = __builtin_amdgcn_rcp(d[c]) + 1.0;
+            else if constexpr (OP == OP_CVT_F64_U32) { d[c] = (double)u[c]; u[c] = u[c] * 3u + (uint32_t)__builtin_bit_cast(uint64_t, d[c]); }
+            else if constexpr (OP == OP_CVT_F32_F64) { f[c] = (float)d[c]; d[c] = d[c] + (double)f[c]; }
+            else if constexpr (OP == OP_FLOOR64) d[c] = __builtin_floor(d[c]) + 0.5;
+            else if constexpr (OP == OP_LDEXP64) d[c] = __builtin_ldexp(d[c], (int)(u[c] & 1u));
+            else if constexpr (OP == OP_CNDMASK) u[c] = (u[c] & 1u) ? u[c] + 7u : u[c] >> 1;
+        }
+    }
+    double acc = 0;
+    for (int c = 0; c < 8; c++) acc += d[c] + f[c] + u[c] + (double)q[c] + p[c].x + p[c].y;
+    out[i] = acc;
+}
+
+// error of the binary32 screens against the binary64 expressions, in units of the guard band:
+// stats[0] = max |diff32 - diff64| / guard, stats[1] = attempts screened, stats[2] = attempts inside the band
+__global__ __launch_bounds__(256) void k_btrs_screen_err(uint64_t seed, int32_t n_lo, uint32_t n_span, double p, unsigned int* stats, unsigned long long* cnt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    Rng g = rng_make(seed, i, 0);
+    uint32_t h[4]; rng_block(g, 9, 0, 0, h);
+    const int32_t n = n_lo + (int32_t)(h[0] % n_span);
+    int32_t x; double pp; bool flip;
+    float worst = 0.f; unsigned int seen = 0, band = 0;
+    if (binom_classify(n, p, x, pp, flip) == BINOM_REJECTION) {
+        const BtrsConsts C = btrs_consts(n, pp, true);
+        for (uint32_t r = 0; r < 64; r++) {
+            uint32_t w[4]; rng_block(g, 1, r, 0, w);
+            for (int half = 0; half < 2; half++) {
+                const double u = u01(w[2 * half]) - 0.5, v = u01(w[2 * half + 1]), us = 0.5 - __builtin_fabs(u);
+                const double kd = btrs_k(C, u, us);
+                if (kd < 0.0 || kd > C.nd || (us >= 0.07 && v <= C.vr) || !(C.scr && kd >= 2.0 && C.nd - kd >= 2.0)) continue;
+                float mag;
+                const float d32 = btrs_screen(C, kd, us, v, mag);
+                const double d64 = btrs_exact_diff(C.nd, C.pp, C.qq, C.m, kd, v, us, C.a, C.b, C.alpha);
+                const float guard = __builtin_fmaf(mag, BTRS_GUARD_REL, BTRS_GUARD_ABS);
+                const float ratio = (float)__builtin_fabs((double)d32 - d64) / guard;
+                worst = ratio > worst ? ratio : worst;
+                seen++; band += __builtin_fabsf(d32) <= guard;
+            }
+        }
+    }
+    atomicMax(&stats[0], __builtin_bit_cast(unsigned int, worst));
+    atomicAdd(&cnt[0], (unsigned long long)seen); atomicAdd(&cnt[1], (unsigned long long)band);
+#endif
+}
+__global__ __launch_bounds__(256) void k_gamma_screen_err(uint64_t seed, double sh_lo, double sh_hi, unsigned int* stats, unsigned long long* cnt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    Rng g = rng_make(seed, i, 0);
+    uint32_t h[4]; rng_block(g, 9, 0, 0, h);
+    const double shape = sh_lo * s_exp(u01(h[0]) * s_log(sh_hi / sh_lo));
+    const GammaConsts G = gamma_consts(shape, true);
+    float worst = 0.f; unsigned int seen = 0, band = 0;
+    for (uint32_t r = 0; r < 64; r++) {
+        uint32_t w[4]; rng_block(g, 1, r, 0, w);
+        float z0, z1; box_muller(w[0], w[1], z0, z1);
+        for (int half = 0; half < 2; half++) {
+            const float xf = half ? z1 : z0;
+            const double x = (double)xf, u = u01(w[2 + half]), t = 1.0 + G.c * x;
+            if (!(t > 0.0)) continue;
+            const double vv = t * t * t, x2 = x * x;
+            if (u < 1.0 - 0.0331 * (x2 * x2)) continue;
+            const float tf = (float)G.c * xf;
+            if (!(tf > -0.9f)) continue;
+            float mag;
+            const float d32 = gamma_screen(tf, (float)G.d, (float)u, mag);
+            const double d64 = s_log(u) - (0.5 * x2 + G.d * (1.0 - vv + s_log(vv)));
+            const float guard = __builtin_fmaf(mag, GAMMA_GUARD_REL, GAMMA_GUARD_ABS);
+            const float ratio = (float)__builtin_fabs((double)d32 - d64) / guard;
+            worst = ratio > worst ? ratio : worst;
+            seen++; band += __builtin_fabsf(d32) <= guard;
+        }
+    }
+    atomicMax(&stats[0], __builtin_bit_cast(unsigned int, worst));
+    atomicAdd(&cnt[0], (unsigned long long)seen); atomicAdd(&cnt[1], (unsigned long long)band);
+#endif
+}
+
 template <class F> double timeit(F f, int iters = 5)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -90,6 +200,46 @@ int main()
         double ns = ms * 1e6 / ((double)n * REP);
         printf("%-34s %8.3f ms  %8.4f ns/draw/chip  %9.1f lane-slots/draw\n", name, ms, ns, ns * 1e-9 * lanes * clk);
     };
+    {
+        std::vector<double> h1(n); for (int64_t i = 0; i < n; i++) h1[i] = 1.5 + (i % 100) * 0.01;
+        CK(hipMemcpy(in, h1.data(), n * 8, hipMemcpyHostToDevice));
+        const int64_t m = 1 << 22;
+        dim3 g2((unsigned)(m / 256));
+        auto rep2 = [&](const char* name, double ms, int per) {
+            // cycles per wave-instruction if one SIMD issues one wave at a time: ms * clk * (SIMDs) / (waves * instrs per wave)
+            double instr = (double)(m / 64) * OPS_REP * 8 * per;
+            printf("%-28s %8.3f ms  %6.2f SIMD-cycles per wave-instruction (statement = %d instr)\n", name, ms, ms * 1e-3 * clk * 1024 / instr, per);
+        };
+#define OPT(OP, per) rep2(#OP, timeit([&] { k_ops<OP><<<g2, blk>>>((double*)in, (double*)out, m); }), per)
+        OPT(OP_FMA64, 1); OPT(OP_MUL64, 1); OPT(OP_ADD64, 1); OPT(OP_FMA32, 1); OPT(OP_PKFMA32, 1); OPT(OP_MAD64, 1); OPT(OP_MULLO, 2); OPT(OP_MULHI, 2);
+        OPT(OP_XOR, 3); OPT(OP_RCP32, 2); OPT(OP_SQRT32, 2); OPT(OP_LOG32, 2); OPT(OP_RCP64, 2); OPT(OP_CVT_F64_U32, 3); OPT(OP_CVT_F32_F64, 3);
+        OPT(OP_FLOOR64, 2); OPT(OP_LDEXP64, 2); OPT(OP_CNDMASK, 4);
+    }
+    {
+        unsigned int* st; unsigned long long* cnt;
+        CK(hipMalloc(&st, 16)); CK(hipMalloc(&cnt, 16));
+        struct { int32_t lo; uint32_t span; double p; } cs[] = {
+            {20, 200, 0.5}, {100, 2000, 0.3}, {2000, 20000, 0.0025}, {2000, 20000, 0.035}, {2000, 20000, 0.127}, {500, 4000, 0.56},
+            {500, 4000, 0.9338}, {500, 4000, 0.0166}, {100000, 900000, 0.0001}, {100000, 900000, 0.5}, {1000000, 15000000, 0.003},
+            {1000000, 15000000, 0.49}, {10000, 100000, 0.9999}, {4000000, 12000000, 0.000003}};
+        for (auto& c : cs) {
+            CK(hipMemset(st, 0, 16)); CK(hipMemset(cnt, 0, 16));
+            k_btrs_screen_err<<<dim3(1 << 14), blk>>>(77, c.lo, c.span, c.p, st, cnt);
+            unsigned int hs[4]; unsigned long long hc[2];
+            CK(hipMemcpy(hs, st, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost));
+            float worst; memcpy(&worst, &hs[0], 4);
+            printf("btrs screen n in [%d,%u) p=%-9g : max error / guard = %.4f   screened %llu, in band %.5f%%\n", c.lo, c.lo + c.span, c.p, worst, hc[0], 100.0 * hc[1] / (double)(hc[0] ? hc[0] : 1));
+        }
+        double gs[][2] = {{1.0, 3.0}, {3.0, 100.0}, {100.0, 1e4}, {1e4, 1e6}, {1e6, 1e8}};
+        for (auto& c : gs) {
+            CK(hipMemset(st, 0, 16)); CK(hipMemset(cnt, 0, 16));
+            k_gamma_screen_err<<<dim3(1 << 14), blk>>>(78, c[0], c[1], st, cnt);
+            unsigned int hs[4]; unsigned long long hc[2];
+            CK(hipMemcpy(hs, st, 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(hc, cnt, 16, hipMemcpyDeviceToHost));
+            float worst; memcpy(&worst, &hs[0], 4);
+            printf("gamma screen shape in [%g,%g) : max error / guard = %.4f   screened %llu, in band %.5f%%\n", c[0], c[1], worst, hc[0], 100.0 * hc[1] / (double)(hc[0] ? hc[0] : 1));
+        }
+    }
     report("philox block", timeit([&] { k_philox<<<grid, blk>>>(1, (uint32_t*)out, n); }));
     report("philox + box-muller pair", timeit([&] { k_bm<<<grid, blk>>>(1, (float*)out, n); }));
     std::vector<double> hx(n); for (int64_t i = 0; i < n; i++) hx[i] = 1.0 + (i % 1000) * 0.37;
