@@ -327,9 +327,11 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
     if (active) {
         S = in[src]; R = in[is + src]; R_pre = R;
         double tm = 0.0, tv = 0.0;
+        int32_t I_next = in[(int64_t)2 * is + src];                                // loads run one bin ahead of their use
 #pragma unroll 1
         for (int i = 0; i < H; i++) {
-            const int32_t Ii = in[(int64_t)(2 + i) * is + src];
+            const int32_t Ii = I_next;
+            if (i + 1 < H) I_next = in[(int64_t)(3 + i) * is + src];
             int32_t already = 0;
             if (D > 0 && i >= 1)
                 for (int r = 0; r < D; r++) already += in[(int64_t)tests_row(H, r, i) * is + src];
@@ -438,6 +440,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
     int32_t sum_inf = 0;
     float z_odd = 0.f;              // second normal / word of the pair block, for the odd term
     uint32_t w_odd = 0u;
+    int32_t I_next = active ? in[(int64_t)(1 + H) * is + src] : 0;                 // bin H-1; loads run one bin ahead
 #pragma unroll 1
     for (int it = 0; it < H; it++) {
         const int i = it == 0 ? H - 1 : it - 1;
@@ -445,7 +448,8 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         if (active) {
             const int2 sp = slots[i * TPB + tid];
             const int32_t sympt = sp.x, pos = sp.y;
-            int32_t Ii = in[(int64_t)(2 + i) * is + src];
+            int32_t Ii = I_next;
+            if (it + 1 < H) I_next = in[(int64_t)(2 + it) * is + src];             // bin of iteration it+1
             double pr = (double)sympt / (double)Ii;                                // simulate.jl:104
             if (pr != pr) pr = 0.0;                                                // simulate.jl:105
             const double om = 1.0 - pr;
