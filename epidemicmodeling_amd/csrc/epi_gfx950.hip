@@ -1591,7 +1591,7 @@ int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed
     return EPI_OK;
 }
 
-int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_local, double* sumsq_local)
+int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_local, double* sumsq_local, uint32_t* flags_local)
 {
     int rc = belief_check(b, "epi_pf_weigh");
     if (rc) return rc;
@@ -1606,6 +1606,7 @@ int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_loc
     HIPCHECK(hipStreamSynchronize(c->stream));
     if (w_local) *w_local = h.w_local;
     if (sumsq_local) *sumsq_local = h.sumsq;
+    if (flags_local) *flags_local = h.flags;
     b->phase = PH_WEIGHED;
     return EPI_OK;
 }

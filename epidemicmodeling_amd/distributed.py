@@ -12,7 +12,8 @@ src/POMDPsInterface.jl:56, src/MPC.jl:393):
   1. local fused weight + step                          (no communication)
   2. all-reduce MAX of the local maximum log weight     (1 double)
   3. local fixed-point weights + prefix sums
-  4. all-gather of the local weight totals and sums of squares (2 values/rank)
+  4. all-gather of the local weight totals, sums of squares and step flags
+     (3 values/rank)
   5. every rank derives the same plan: shard g's particles are the ancestors of
      global slots [lo[g], lo[g+1])
   6. slots of that range owned by another rank: the resampled particles are
@@ -66,9 +67,9 @@ class LibShard:
         return v.value
 
     def weigh(self, lwmax):
-        w, sq = C.c_uint64(), C.c_double()
-        check(self.lib.epi_pf_weigh(self.ctx.handle, self.b.handle, lwmax, C.byref(w), C.byref(sq)))
-        return w.value, sq.value
+        w, sq, fl = C.c_uint64(), C.c_double(), C.c_uint32()
+        check(self.lib.epi_pf_weigh(self.ctx.handle, self.b.handle, lwmax, C.byref(w), C.byref(sq), C.byref(fl)))
+        return w.value, sq.value, fl.value
 
     def plan(self, n_total, w_shard, seed, step):
         G = len(w_shard)
@@ -160,14 +161,19 @@ class ShardedFilter:
         # 1-2: fused weight + step, global maximum log weight
         t = torch.tensor([sh.predict(a, o, seed, step)], dtype=torch.float64, device=self.comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        lwmax = float(t[0])
+        lwmax = t.item()
         # 3-4: local fixed-point weights, totals of every shard
-        w_local, sq_local = sh.weigh(lwmax)
-        mine = torch.tensor([float(w_local), sq_local], dtype=torch.float64, device=self.comm_device)   # totals are < 2^53: exact
-        allv = [torch.empty_like(mine) for _ in range(G)]
-        dist.all_gather(allv, mine)
-        w_shard = [int(v[0]) for v in allv]
-        sumsq = math.fsum(float(v[1]) for v in allv)
+        w_local, sq_local, fl_local = sh.weigh(lwmax)
+        # totals are < 2^53 and flags < 2^32: exact as doubles
+        mine = torch.tensor([float(w_local), sq_local, float(fl_local)], dtype=torch.float64, device=self.comm_device)
+        allv = torch.empty(3 * G, dtype=torch.float64, device=self.comm_device)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.cpu().tolist()                                         # one device-to-host copy
+        w_shard = [int(allv[3 * h]) for h in range(G)]
+        sumsq = math.fsum(allv[3 * h + 1] for h in range(G))
+        flags = 0
+        for h in range(G):
+            flags |= int(allv[3 * h + 2])
         # 5: the plan (identical on every rank)
         lo = sh.plan(self.n_total, w_shard, seed, step)
         st = self.starts
@@ -192,12 +198,10 @@ class ShardedFilter:
         s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
         if s1 > s0:
             sh.select_local(g, w_shard, seed, step, s0, s1)
-        flags = sh.finish()
-        # OR of the per-rank flag words as a MAX over their bits (RCCL has no bitwise reductions)
-        ft = torch.tensor([(flags >> k) & 1 for k in range(8)], dtype=torch.int64, device=self.comm_device)
-        dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+        sh.finish()
         W = sum(w_shard)
-        flags = sum(int(ft[k]) << k for k in range(8)) | (_lib.EPI_F_ZERO_W if W == 0 else 0)
+        if W == 0:
+            flags |= _lib.EPI_F_ZERO_W
         self.step += 1
         loglik = (lwmax + math.log(W / 2.0 ** self.frac_bits / self.n_total) - 0.5 * math.log(2 * math.pi)) if W else float("-inf")
         return {"loglik": loglik, "ess": (float(W) ** 2 / sumsq) if sumsq > 0 else 0.0, "flags": flags,

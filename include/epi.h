@@ -171,8 +171,10 @@ int epi_pf_update(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t see
  *   1. epi_pf_predict : fused weight + step of the local particles;
  *                       returns the local maximum log weight.
  *   2. epi_pf_weigh   : fixed-point weights relative to the GLOBAL maximum and
- *                       their local prefix sums; returns the local weight total
- *                       and sum of squares.  frac_bits = epi_pf_frac_bits(n_total).
+ *                       their local prefix sums; returns the local weight total,
+ *                       sum of squares and the EPI_F_* flags the local step raised
+ *                       (so that one all-gather carries everything the ranks
+ *                       exchange).  frac_bits = epi_pf_frac_bits(n_total).
  *   3. epi_pf_plan    : given the weight totals of all G shards, the global
  *                       output-slot range [lo[g], lo[g+1]) whose ancestors live
  *                       in shard g (host arithmetic, identical on every rank).
@@ -184,7 +186,8 @@ int epi_pf_update(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t see
  *   5. epi_pf_finish  : close the update (swap buffers, collect flags). */
 int epi_pf_frac_bits(int64_t n_total);
 int epi_pf_predict(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step, double *lwmax_local);
-int epi_pf_weigh(epi_ctx *ctx, epi_belief *b, double lwmax_global, uint64_t *w_local, double *sumsq_local);
+int epi_pf_weigh(epi_ctx *ctx, epi_belief *b, double lwmax_global, uint64_t *w_local, double *sumsq_local,
+                 uint32_t *flags_local);
 int epi_pf_plan(int64_t n_total, int n_shards, const uint64_t *w_shard, uint64_t seed, uint32_t step,
                 int64_t *lo /* n_shards + 1 */);
 int epi_pf_select_local(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const uint64_t *w_shard,

@@ -52,7 +52,7 @@ class OracleShard:
         self.L.orc_quantize(self.n, self.lw.ctypes.data_as(_f64p), lwmax, F, wq.ctypes.data_as(_u64p))
         self.cum = np.cumsum(wq.astype(object)).astype(np.uint64) if self.n else wq
         w = wq.astype(np.float64)
-        return int(self.cum[-1]), float((w * w).sum())
+        return int(self.cum[-1]), float((w * w).sum()), int(self.flags)
 
     def _tq(self, m, W, u):
         stepw = np.float64(W) / np.float64(self.n_total)

@@ -268,7 +268,7 @@ def test_pf_sharded_phases_equal_single_update():
         w = (C.c_uint64 * G)()
         for g, b in enumerate(shards):
             wl, sq = C.c_uint64(), C.c_double()
-            check(lib.epi_pf_weigh(ctx.handle, b.handle, gmax, C.byref(wl), C.byref(sq)))
+            check(lib.epi_pf_weigh(ctx.handle, b.handle, gmax, C.byref(wl), C.byref(sq), None))
             w[g] = wl.value
         lo = (C.c_int64 * (G + 1))()
         check(lib.epi_pf_plan(n, G, w, seed, step, lo))
@@ -360,3 +360,88 @@ def test_large_belief_properties():
     assert (S == S2).all() and (I == I2).all() and (R == R2).all()
     m = em.mean(b)
     assert m.S == int(np.rint(S.sum() / n)) and (m.I == np.rint(I.sum(axis=0) / n)).all()
+
+
+# ---------------------------------------------------------------------------
+# kernel variants: every implementation choice must leave the results unchanged
+# ---------------------------------------------------------------------------
+def _three_updates(pomdp, n):
+    b = em.initialbelief(pomdp, n, seed=SEED)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    info = []
+    for day in range(3):
+        em.update(upd, b, em.Action(0.2), 9000 - 300 * day)
+        info.append((upd.last_ess, upd.last_flags))
+    out = b.download()
+    b.close()
+    return out, info
+
+
+@pytest.mark.parametrize("delay", [0, 1])
+def test_step_implementations_and_screens_agree(delay):
+    """Cooperative (LDS retry queues) vs one-thread-per-particle kernel, binary32 screens on vs
+    off: four builds of the same update, bit-identical posteriors at 10^6 particles."""
+    lib = _lib.load()
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    n = 1_000_000
+    try:
+        ref, ref_info = _three_updates(pomdp, n)
+        for coop, screen in ((1, 0), (0, 1), (0, 0)):
+            check(lib.epi_debug_step_impl(coop))
+            check(lib.epi_debug_screen(screen))
+            got, info = _three_updates(pomdp, n)
+            _eq(got, ref)
+            assert info == ref_info
+    finally:
+        check(lib.epi_debug_step_impl(1))
+        check(lib.epi_debug_screen(1))
+
+
+def test_wide_state_retry_queue_overflow_bit_exact():
+    """H = 56 infection ages: 112 binomial draws per particle, so a workgroup's rejected first
+    attempts exceed the retry queue and the in-thread completion path runs; still bit-exact."""
+    pomdp = em.make_pomdp(LOD=5, horizon=56, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 3000
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 5)
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    _, mu, _ = orc.log_weights(st, 0.3, 0)
+    o = int(np.median(mu))
+    for step in range(3):
+        em.update(upd, b, em.Action(0.3), o)
+        st, info = orc.pf_update(st, 0.3, o, SEED, step)
+        assert upd.last_flags == info["flags"]
+    _eq(b.download(), st)
+
+
+def test_sharded_filter_over_rccl_single_rank(tmp_path):
+    """ShardedFilter with the device shard and the nccl (RCCL) backend, world size 1: the
+    collectives run on device tensors and the posterior equals the oracle's single update."""
+    import torch
+    import torch.distributed as dist
+    from epidemicmodeling_amd.distributed import ShardedFilter
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n, a = 20_000, 0.25
+    st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
+    _, mu, _ = orc.log_weights(st, a, 0)
+    obs = [int(np.quantile(mu, q)) for q in (0.8, 0.5)]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/pg", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        f = ShardedFilter(pomdp, n, seed=SEED, device=0)
+        f.init_normal(10_000.0, 5_000.0)
+        exp = st
+        for step, o in enumerate(obs):
+            info = f.update(a, o)
+            exp, einfo = orc.pf_update(exp, a, o, SEED, step)
+            assert info["flags"] == einfo["flags"] and abs(info["ess"] - einfo["ess"]) <= 1e-9 * einfo["ess"]
+            assert np.isfinite(info["loglik"])
+        _eq(f.download_local(), exp)
+        mS, mI, mR, mT = f.mean()
+        eS, eI, eR, eT, _ = orc.mean(exp)
+        assert mS == eS and mR == eR and (mI == eI).all()
+    finally:
+        dist.destroy_process_group()
