@@ -4,12 +4,12 @@ behind the reference's own gen / update / mean interface."""
 from .params import (Action, State, CovidPOMDP, make_pomdp, unity_test_period, population, Array,
                      State_from, State_random)
 from .interface import (Context, ParticleCollection, BootstrapFilter, update, gen, observation, initialbelief,
-                        random_states, mean, n_particles, particles, rand, step_batch, rollout_batch, SimHist,
+                        random_states, mean, n_particles, particles, rand, step_batch, rollout_batch, rollout_score, RandomShootingPlanner, SimHist,
                         Simulate, SimulateEnsemble, SimulateClosedLoop)
 
 __all__ = [
     "Action", "State", "CovidPOMDP", "make_pomdp", "unity_test_period", "population", "Array", "State_from",
     "State_random", "Context", "ParticleCollection", "BootstrapFilter", "update", "gen", "observation",
-    "initialbelief", "random_states", "mean", "n_particles", "particles", "rand", "step_batch", "rollout_batch",
+    "initialbelief", "random_states", "mean", "n_particles", "particles", "rand", "step_batch", "rollout_batch", "rollout_score", "RandomShootingPlanner",
     "SimHist", "Simulate", "SimulateEnsemble", "SimulateClosedLoop",
 ]

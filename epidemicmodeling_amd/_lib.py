@@ -71,6 +71,8 @@ SIGNATURES = {
     "epi_sample_gamma": (C.c_int, [_vp, C.c_int64, _f64p, _f64p, C.c_uint64, C.c_uint32, C.c_uint32, _f64p]),
     "epi_rollout_batch": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint32,
                                     _i64p, _f64p, _u32p]),
+    "epi_rollout_score": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, _f64p, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                                    _f64p, _u32p]),
     "epi_pf_update": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p]),
     "epi_pf_frac_bits": (C.c_int, [C.c_int64]),
     "epi_pf_predict": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p]),

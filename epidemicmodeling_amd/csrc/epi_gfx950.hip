@@ -148,9 +148,10 @@ struct StepArgs {
     const int32_t* in; int64_t in_stride;
     const int32_t* anc;         // source column of each particle in `in`, or null = identity
     int32_t* out; int64_t out_stride;
-    double a; const double* a_dev; int64_t a_row_stride;   // action: scalar or a_dev[m * a_row_stride + a_col]
+    double a; const double* a_dev; int64_t a_row_stride;   // action: scalar or a_dev[row(m) * a_row_stride + a_col]
     int64_t a_col;
-    double a_prev; const double* a_prev_dev; int64_t a_prev_col;   // previous action: scalar or a_prev_dev[m * a_row_stride + a_prev_col]
+    int64_t a_div;              // row(m) = m / a_div when a_div > 1 (consecutive particles share an action row), else m
+    double a_prev; const double* a_prev_dev; int64_t a_prev_col;   // previous action: scalar or a_prev_dev[row(m) * a_row_stride + a_prev_col]
     uint64_t seed; uint32_t step; uint64_t slot0;
     // filter
     double o; double* lw; DevScalars* scal;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const DevParams*
     unsigned int flags = 0;
     if (m < A.n) {
         const int64_t src = A.anc ? (int64_t)A.anc[m] : m;
-        const double a = A.a_dev ? A.a_dev[m * A.a_row_stride + A.a_col] : A.a;
+        const int64_t arow = A.a_div > 1 ? m / A.a_div : m;
+        const double a = A.a_dev ? A.a_dev[arow * A.a_row_stride + A.a_col] : A.a;
         StepResult res;
         int32_t s_pre = 0, r_pre = 0, suminf_pre = 0;
         if (A.hist) {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(TPB) void k_step(const StepArgs A, const DevParams*
         if (A.o_out) A.o_out[m] = res.o;
         if (A.newinf_out) A.newinf_out[m] = res.new_inf;
         if (A.r_out) {
-            double ap = A.a_prev_dev ? A.a_prev_dev[m * A.a_row_stride + A.a_prev_col] : A.a_prev;
+            double ap = A.a_prev_dev ? A.a_prev_dev[arow * A.a_row_stride + A.a_prev_col] : A.a_prev;
             A.r_out[m] = reward_of(P, res.sum_inf, a, ap);
         }
         if (A.hist) {
@@ -312,7 +314,8 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
     const int64_t m = base + tid;
     const bool active = m < A.n;
     const int64_t src = active ? (A.anc ? (int64_t)A.anc[m] : m) : 0;
-    const double a = active ? (A.a_dev ? A.a_dev[m * A.a_row_stride + A.a_col] : A.a) : 0.0;
+    const int64_t arow = A.a_div > 1 ? m / A.a_div : m;
+    const double a = active ? (A.a_dev ? A.a_dev[arow * A.a_row_stride + A.a_col] : A.a) : 0.0;
     const Rng g = rng_make(A.seed, A.slot0 + (uint64_t)m, A.step);
     const bool screen = A.screen != 0;
     const int32_t* __restrict__ in = A.in;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         if (A.o_out) A.o_out[m] = o_sum;
         if (A.newinf_out) A.newinf_out[m] = newi;
         if (A.r_out) {
-            const double ap = A.a_prev_dev ? A.a_prev_dev[m * A.a_row_stride + A.a_prev_col] : A.a_prev;
+            const double ap = A.a_prev_dev ? A.a_prev_dev[arow * A.a_row_stride + A.a_prev_col] : A.a_prev;
             A.r_out[m] = reward_of(P, sum_inf + newi, a, ap);
         }
         if (A.hist) { A.hist[m] = S; A.hist[A.n + m] = suminf_pre; A.hist[2 * A.n + m] = R_pre; A.hist[3 * A.n + m] = o_sum; }
@@ -773,6 +776,36 @@ __global__ __launch_bounds__(TPB) void k_gather(int64_t n, const int32_t* __rest
 }
 
 // sums[row] += sum over particles of state[row][anc[m]]; blockIdx.y = row
+// trajectory m starts from particle (m mod n_start) of a belief (through its ancestor index)
+__global__ __launch_bounds__(TPB) void k_replicate(int64_t n, const int32_t* __restrict__ src, int64_t src_stride, const int32_t* __restrict__ anc,
+                                                    int64_t n_start, int32_t* __restrict__ dst, int64_t dst_stride, int rows)
+{
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (m >= n) return;
+    const int64_t p = m % n_start;
+    const int64_t s = anc ? (int64_t)anc[p] : p;
+    for (int r = 0; r < rows; r++) dst[(int64_t)r * dst_stride + m] = src[(int64_t)r * src_stride + s];
+}
+
+// acc[m] = (first ? 0 : acc[m]) + scale * r[m]   (two roundings: product, then sum)
+__global__ __launch_bounds__(TPB) void k_score_acc(int64_t n, double* __restrict__ acc, const double* __restrict__ r, double scale, int first)
+{
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (m >= n) return;
+    const double t = scale * r[m];
+    acc[m] = first ? t : acc[m] + t;
+}
+
+// score[s] = (acc[s R] + acc[s R + 1] + ... in that order) / R
+__global__ __launch_bounds__(TPB) void k_score_mean(int64_t n_seq, int R, const double* __restrict__ acc, double* __restrict__ score)
+{
+    const int64_t s = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (s >= n_seq) return;
+    double t = 0.0;
+    for (int r = 0; r < R; r++) t += acc[s * R + r];
+    score[s] = t / (double)R;
+}
+
 __global__ __launch_bounds__(TPB) void k_sums(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
                                                long long* __restrict__ sums)
 {
@@ -1427,6 +1460,55 @@ int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, i
         for (int64_t p = 0; p < n; p++)
             for (int t = 0; t < T; t++) rew[p * T + t] = h[(size_t)t * (size_t)n + (size_t)p];
     }
+    rc = fetch_flags(c, flags, true);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
+}
+
+int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts_per_seq, int T, const double* actions, double a_prev0,
+                      double discount, uint64_t seed, uint32_t step0, double* score, uint32_t* flags)
+{
+    int rc = belief_check(start, "epi_rollout_score");
+    if (rc) return rc;
+    if (!c || start->ctx != c || !actions || !score || T < 1 || n_seq < 1 || rollouts_per_seq < 1)
+        return fail(EPI_EINVAL, "epi_rollout_score: bad argument");
+    if (start->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_rollout_score: a phased update is in progress");
+    const int64_t n = n_seq * (int64_t)rollouts_per_seq;
+    if (n >= (1LL << 31)) return fail(EPI_ERANGE, "epi_rollout_score: n_seq * rollouts_per_seq must be < 2^31");
+    HIPCHECK(hipSetDevice(c->device));
+    const int rows = start->rows;
+    const int64_t stride = ceil_div(n, 64) * 64;
+    DevBuf dact, dst[2], drew, dacc, dscore;
+    const size_t sbytes = sizeof(int32_t) * (size_t)rows * (size_t)stride;
+    if (dact.alloc(sizeof(double) * (size_t)n_seq * (size_t)T) != hipSuccess || dst[0].alloc(sbytes) != hipSuccess || dst[1].alloc(sbytes) != hipSuccess ||
+        drew.alloc(sizeof(double) * (size_t)n) != hipSuccess || dacc.alloc(sizeof(double) * (size_t)n) != hipSuccess ||
+        dscore.alloc(sizeof(double) * (size_t)n_seq) != hipSuccess)
+        return fail(EPI_ENOMEM, "epi_rollout_score: hipMalloc failed");
+    HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * (size_t)n_seq * (size_t)T, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)ceil_div(n, TPB)), blk(TPB);
+    k_replicate<<<grid, blk, 0, c->stream>>>(n, start->buf[start->cur], start->stride, start->has_anc ? start->anc : nullptr, start->n,
+                                             dst[0].as<int32_t>(), stride, rows);
+    HIPCHECK(hipGetLastError());
+    double scale = 1.0;
+    for (int t = 0; t < T; t++) {
+        StepArgs A;
+        memset(&A, 0, sizeof A);
+        A.screen = g_screen;
+        A.n = n; A.in = dst[t & 1].as<int32_t>(); A.in_stride = stride;
+        A.out = dst[(t & 1) ^ 1].as<int32_t>(); A.out_stride = stride;
+        A.a_dev = dact.as<double>(); A.a_row_stride = T; A.a_col = t; A.a_div = rollouts_per_seq;
+        if (t == 0) A.a_prev = a_prev0;
+        else { A.a_prev_dev = dact.as<double>(); A.a_prev_col = t - 1; }
+        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = 0; A.scal = c->d_scal;
+        A.r_out = drew.as<double>();
+        HIPCHECK(launch_step<false>(c, A));
+        k_score_acc<<<grid, blk, 0, c->stream>>>(n, dacc.as<double>(), drew.as<double>(), scale, t == 0);
+        scale *= discount;
+    }
+    k_score_mean<<<dim3((unsigned)ceil_div(n_seq, TPB)), blk, 0, c->stream>>>(n_seq, rollouts_per_seq, dacc.as<double>(), dscore.as<double>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(score, dscore.p, sizeof(double) * (size_t)n_seq, hipMemcpyDeviceToHost, c->stream));
     rc = fetch_flags(c, flags, true);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));

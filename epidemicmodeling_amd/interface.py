@@ -339,6 +339,53 @@ def rollout_batch(b: ParticleCollection, T: int, actions, seed: int = _DEFAULT_S
     return hist, rew, flags.value
 
 
+def rollout_score(b: ParticleCollection, actions, rollouts_per_seq: int = 1, discount: Optional[float] = None,
+                  seed: int = _DEFAULT_SEED, step0: int = 0):
+    """Scores action sequences by rollouts from the belief b (unchanged): actions is [n_seq, T];
+    every sequence gets rollouts_per_seq independent T-day rollouts, trajectory j starting from
+    particle j mod n of b.  Returns (score[n_seq], flags): score = mean over the sequence's rollouts
+    of sum_t discount^t reward_t (reward: src/simulate.jl:153-158; discount: src/typedef.jl:82).
+    This is the batched form of the rollouts a tree-search or random-shooting planner makes
+    (planner call site src/POMDPsInterface.jl:44)."""
+    act = np.ascontiguousarray(np.asarray(actions, dtype=np.float64))
+    if act.ndim != 2:
+        raise ValueError("actions must be [n_seq, T]")
+    n_seq, T = act.shape
+    disc = b.ctx.pomdp.discount if discount is None else float(discount)
+    score = np.empty(n_seq, dtype=np.float64)
+    flags = C.c_uint32()
+    check(b.ctx.lib.epi_rollout_score(b.ctx.handle, b.handle, n_seq, int(rollouts_per_seq), T, as_f64p(act),
+                                      b.prev_action.testing_prop, disc, seed, step0, as_f64p(score), C.byref(flags)))
+    return score, flags.value
+
+
+class RandomShootingPlanner:
+    """A planner in the sense of POMDPs.action(planner, b) (src/POMDPsInterface.jl:44): draws n_seq
+    action sequences, piecewise constant over test_period days with levels 0:0.1:1, scores them on
+    the device with rollouts from the belief and returns the first action of the best sequence."""
+
+    def __init__(self, pomdp: CovidPOMDP, n_seq: int = 1000, rollouts_per_seq: int = 64, horizon: int = 20,
+                 seed: int = _DEFAULT_SEED):
+        self.pomdp, self.n_seq, self.rollouts_per_seq, self.horizon, self.seed = pomdp, n_seq, rollouts_per_seq, horizon, seed
+        self.calls = 0
+        self.last_scores = None
+        self.last_sequences = None
+
+    def sequences(self) -> np.ndarray:
+        rng = np.random.default_rng([self.seed, self.calls])
+        period = max(1, self.pomdp.test_period)
+        blocks = -(-self.horizon // period)
+        levels = rng.integers(0, 11, size=(self.n_seq, blocks)) / 10.0
+        return np.repeat(levels, period, axis=1)[:, :self.horizon]
+
+    def action(self, b: ParticleCollection) -> Action:
+        seqs = self.sequences()
+        score, _ = rollout_score(b, seqs, self.rollouts_per_seq, seed=self.seed ^ 0x9E3779B97F4A7C15, step0=self.calls * self.horizon)
+        self.calls += 1
+        self.last_scores, self.last_sequences = score, seqs
+        return Action(float(seqs[int(np.argmax(score)), 0]))
+
+
 def Simulate(T: int, state: State, params: CovidPOMDP, action: Action, seed: int = _DEFAULT_SEED, device: int = 0) -> SimHist:
     """Simulate(T, state, params, action) (src/simulate.jl:175-196)."""
     b = ParticleCollection.from_states(params, [state], device)

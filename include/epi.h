@@ -154,6 +154,18 @@ int epi_rollout_batch(epi_ctx *ctx, epi_belief *b, int T,
                       uint64_t seed, uint32_t step0,
                       int64_t *hist, double *rew, uint32_t *flags);
 
+/* Scenario scoring for planners (the batched form of the rollouts POMCPOW and random-shooting MPC
+ * make from the belief: planner call sites src/POMDPsInterface.jl:44, test/POMCPOWtest.jl:15-21,
+ * horizon src/MPC.jl:58): n_seq action sequences x rollouts_per_seq independent T-day rollouts
+ * each.  Trajectory j (0 <= j < n_seq * rollouts_per_seq) follows sequence j / rollouts_per_seq
+ * (actions is n_seq x T, row-major), starts from particle (j mod n) of `start` (unchanged) and
+ * draws from the streams of slot j, steps step0 .. step0+T-1.
+ * score[s] = mean over the sequence's rollouts (summed in rollout order) of
+ * sum_t discount^t * reward_t (src/simulate.jl:153-158), discount^t by repeated multiplication. */
+int epi_rollout_score(epi_ctx *ctx, epi_belief *start, int64_t n_seq, int rollouts_per_seq, int T,
+                      const double *actions, double a_prev0, double discount, uint64_t seed, uint32_t step0,
+                      double *score /* n_seq */, uint32_t *flags);
+
 /* ---- the bootstrap filter update ---------------------------------------------- */
 
 /* update(BootstrapFilter(pomdp, n), b, a, o) (ParticleFilters.jl; call sites

@@ -310,6 +310,40 @@ def test_rollout_bit_exact():
         assert (rew.view(np.uint64) == erew.view(np.uint64)).all()
 
 
+@pytest.mark.parametrize("n_start", [1, 37])
+def test_rollout_score_bit_exact(n_start):
+    """Scenario scoring: sequences x rollouts from a belief, discounted reward summed on the device,
+    against the oracle's rollouts of the same trajectories reduced in the same order."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=1, test_period=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n_seq, R, T, disc = 23, 5, 9, 0.95
+    st = orc.init_normal(n_start, 10_000.0, 5_000.0, 11)
+    rng = np.random.default_rng(3)
+    actions = rng.integers(0, 11, size=(n_seq, T)) / 10.0
+    b = _belief(pomdp, st)
+    score, fl = em.rollout_score(b, actions, R, discount=disc, seed=99, step0=4)
+    _eq(b.download(), st)                                           # the belief is left as it was
+    n = n_seq * R
+    idx = np.arange(n) % n_start
+    start = tuple(x[idx] for x in st)
+    _, _, rew, efl = orc.rollout(start, T, np.repeat(actions, R, axis=0), a_prev0=0.0, seed=99, step0=4)
+    acc = np.zeros(n)
+    scale = 1.0
+    for t in range(T):
+        acc = scale * rew[:, t] if t == 0 else acc + scale * rew[:, t]
+        scale *= disc
+    exp = np.zeros(n_seq)
+    for r in range(R):
+        exp = exp + acc.reshape(n_seq, R)[:, r]
+    exp = exp / R
+    assert fl == efl
+    assert (score.view(np.uint64) == exp.view(np.uint64)).all()
+    planner = em.RandomShootingPlanner(pomdp, n_seq=64, rollouts_per_seq=4, horizon=6, seed=5)
+    a = planner.action(b)
+    assert 0.0 <= a.testing_prop <= 1.0 and planner.last_scores.shape == (64,)
+    assert a.testing_prop == planner.last_sequences[int(np.argmax(planner.last_scores)), 0]
+
+
 def test_reference_bounds_property_on_device():
     """test/InfectionSimTest.jl:14-30 through Simulate(): 0 <= S, sum(I), R <= N for
     7 parameter sets x 6 actions, T = 100."""
