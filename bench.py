@@ -114,6 +114,8 @@ def run_sharded(args):
     import epidemicmodeling_amd as em
     from epidemicmodeling_amd.distributed import ShardedFilter
 
+    if "RANK" not in os.environ:          # --sharded on one GPU without a launcher: a group of one
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
@@ -152,12 +154,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--sharded", action="store_true",
+                    help="use the sharded (torch.distributed) update even with one GPU, to measure its host overhead")
     ap.add_argument("--calibrate", action="store_true",
                     help="after the timed region, run one gather dispatch of known traffic (PMC calibration)")
     args = ap.parse_args()
 
     rank = 0
-    if args.gpus > 1:
+    if args.gpus > 1 or args.sharded:
         pomdp, n, dt, kms, diag, rank = run_sharded(args)
     else:
         pomdp, n, dt, kms, diag = run_single(args)

@@ -8,8 +8,9 @@
 //   k_wsum        fixed-point weights: per-workgroup totals
 //   k_wscan       single-workgroup exclusive scan of those totals
 //   k_wcum        fixed-point weights again + workgroup prefix scan -> C[i]
-//   k_select      systematic resampling: ancestor of every output slot by
-//                 binary search in C
+//   k_scatter     systematic resampling from the ancestors' side: every particle
+//                 writes its index into the contiguous output slots it owns
+//                 (k_scatter_big: the long ranges of collapsed weights)
 //   k_export / k_import / k_gather   move resampled particles
 //   k_sums        integer column sums (belief mean)
 //   k_init_*      initial particles
@@ -99,6 +100,7 @@ struct epi_belief {
     double* lw = nullptr;               // log weights, then (same memory) uint64 cumulative weights
     unsigned long long* blocksum = nullptr;
     double* blocksq = nullptr;
+    unsigned long long* big = nullptr;  // [0] = number of listed long child ranges, then the ranges (k_scatter)
     int64_t nblocks = 0;
     int phase = PH_IDLE;
     int64_t halo_used = 0;
@@ -735,14 +737,73 @@ __device__ __forceinline__ int64_t find_ancestor(const unsigned long long* __res
     return lo > n_local - 1 ? n_local - 1 : lo;
 }
 
-__global__ __launch_bounds__(TPB) void k_select(int64_t count, int64_t slot_begin, int64_t slot0, const unsigned long long* __restrict__ cum,
-                                                 int64_t n_local, const DevScalars* __restrict__ scal, int64_t n_total, double u,
-                                                 int32_t* __restrict__ anc)
+// The same assignment from the ancestors' side, without a search: particle i is the ancestor of the
+// contiguous slots m with C_{i-1} <= floor(T_m) < C_i, i.e. of [first_slot(C_{i-1}), first_slot(C_i)),
+// first_slot(c) = the first slot whose position reaches c.  Every owned slot in [slot_lo, slot_hi) is
+// written exactly once.  A particle writes a few children itself, a wave shares the work of a particle
+// with up to BIG_RANGE children, and longer ranges (collapsed weights) are listed for k_scatter_big.
+struct BigRange { long long a, b; long long idx; };
+constexpr int SMALL_RANGE = 8, BIG_RANGE = 8192;
+
+__device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw, double u, int64_t n_total)
 {
-    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (j >= count) return;
-    const int64_t m = slot_begin + j;
-    anc[m - slot0] = (int32_t)find_ancestor(cum, n_local, scal, n_total, u, m, slot0);
+    const double guess = __builtin_ceil((double)c / stepw - u);
+    int64_t m = guess < 0.0 ? 0 : (guess > (double)n_total ? n_total : (int64_t)guess);
+    while (m > 0 && (unsigned long long)__builtin_floor(((double)(m - 1) + u) * stepw) >= c) m--;
+    while (m < n_total && (unsigned long long)__builtin_floor(((double)m + u) * stepw) < c) m++;
+    return m;
+}
+
+__global__ __launch_bounds__(TPB) void k_scatter(int64_t n_local, const unsigned long long* __restrict__ cum, const DevScalars* __restrict__ scal,
+                                                  int64_t n_total, double u, int64_t slot_lo, int64_t slot_hi, int64_t slot0,
+                                                  int32_t* __restrict__ anc, unsigned long long* __restrict__ big_count, BigRange* __restrict__ big)
+{
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const bool act = i < n_local;
+    const unsigned long long W = scal->w_total;
+    if (W == 0ULL) {                        // every weight zero: keep the particle in place
+        if (act && slot0 + i >= slot_lo && slot0 + i < slot_hi) anc[i] = (int32_t)i;
+        return;
+    }
+    const double stepw = (double)W / (double)n_total;
+    const unsigned long long off = scal->w_off;
+    const int lane = threadIdx.x & 63;
+    int64_t b = slot_hi;
+    if (act && i < n_local - 1) b = first_slot(off + cum[i], stepw, u, n_total);
+    int64_t a = (int64_t)shfl_up_u64((unsigned long long)b, 1);
+    if (lane == 0) a = (act && i > 0) ? first_slot(off + cum[i - 1], stepw, u, n_total) : slot_lo;
+    if (i == 0) a = slot_lo;
+    a = a < slot_lo ? slot_lo : a;
+    b = b > slot_hi ? slot_hi : b;
+    const int64_t len = act ? b - a : 0;
+    int32_t* dst = anc + (a - slot0);
+    if (len > 0 && len <= SMALL_RANGE)
+        for (int64_t k = 0; k < len; k++) dst[k] = (int32_t)i;
+    unsigned long long mask = __ballot(len > SMALL_RANGE && len <= BIG_RANGE);
+    while (mask) {
+        const int l = __ffsll((long long)mask) - 1;
+        mask &= mask - 1ULL;
+        const int64_t a_l = (int64_t)__shfl((unsigned int)(a >> 32), l, 64) << 32 | (int64_t)__shfl((unsigned int)a, l, 64);
+        const int len_l = __shfl((int)len, l, 64);
+        const int idx_l = __shfl((int)i, l, 64);
+        for (int k = lane; k < len_l; k += 64) anc[a_l - slot0 + k] = idx_l;
+    }
+    if (len > BIG_RANGE) {
+        const unsigned long long pos = atomicAdd(big_count, 1ULL);
+        big[pos] = BigRange{(long long)a, (long long)b, (long long)i};
+    }
+}
+
+// the listed long ranges, each spread over the whole grid
+__global__ __launch_bounds__(TPB) void k_scatter_big(const unsigned long long* __restrict__ big_count, const BigRange* __restrict__ big,
+                                                      int64_t slot0, int32_t* __restrict__ anc)
+{
+    const unsigned long long cnt = *big_count;
+    for (unsigned long long e = 0; e < cnt; e++) {
+        const BigRange r = big[e];
+        for (long long m = r.a + (long long)blockIdx.x * TPB + threadIdx.x; m < r.b; m += (long long)gridDim.x * TPB)
+            anc[m - slot0] = (int32_t)r.idx;
+    }
 }
 
 // resampled particles of slots [slot_begin, slot_begin + count) packed as dst[row * count + j]
@@ -775,7 +836,6 @@ __global__ __launch_bounds__(TPB) void k_gather(int64_t n, const int32_t* __rest
     for (int r = 0; r < rows; r++) dst[(int64_t)r * stride + m] = src[(int64_t)r * stride + a];
 }
 
-// sums[row] += sum over particles of state[row][anc[m]]; blockIdx.y = row
 // trajectory m starts from particle (m mod n_start) of a belief (through its ancestor index)
 __global__ __launch_bounds__(TPB) void k_replicate(int64_t n, const int32_t* __restrict__ src, int64_t src_stride, const int32_t* __restrict__ anc,
                                                     int64_t n_start, int32_t* __restrict__ dst, int64_t dst_stride, int rows)
@@ -806,6 +866,7 @@ __global__ __launch_bounds__(TPB) void k_score_mean(int64_t n_seq, int R, const 
     score[s] = t / (double)R;
 }
 
+// sums[row] += sum over particles of state[row][anc[m]]; blockIdx.y = row
 __global__ __launch_bounds__(TPB) void k_sums(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
                                                long long* __restrict__ sums)
 {
@@ -1029,6 +1090,7 @@ int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief*
     if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)n_local);
     if (e == hipSuccess) e = hipMalloc((void**)&b->blocksum, sizeof(unsigned long long) * (size_t)b->nblocks);
     if (e == hipSuccess) e = hipMalloc((void**)&b->blocksq, sizeof(double) * (size_t)b->nblocks);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->big, 16 + 24 * ((size_t)n_local / 8192 + 2));
     if (e != hipSuccess) {
         epi_belief_destroy(b);
         return fail(EPI_ENOMEM, "epi_belief_create: hipMalloc failed: %s", hipGetErrorString(e));
@@ -1050,6 +1112,7 @@ int epi_belief_destroy(epi_belief* b)
     if (b->anc) (void)hipFree(b->anc);
     if (b->lw) (void)hipFree(b->lw);
     if (b->blocksum) (void)hipFree(b->blocksum);
+    if (b->big) (void)hipFree(b->big);
     if (b->blocksq) (void)hipFree(b->blocksq);
     delete b;
     return EPI_OK;
@@ -1561,6 +1624,20 @@ static int launch_weigh(epi_ctx* c, epi_belief* b)
     return EPI_OK;
 }
 
+// ancestors of the owned slots [slot_lo, slot_hi) from the local cumulative weights
+static int launch_scatter(epi_ctx* c, epi_belief* b, double u, int64_t slot_lo, int64_t slot_hi)
+{
+    HIPCHECK(hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream));
+    BigRange* list = reinterpret_cast<BigRange*>(b->big + 2);
+    k_scatter<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, reinterpret_cast<const unsigned long long*>(b->lw), c->d_scal,
+                                                                               b->n_total, u, slot_lo, slot_hi, b->slot0, b->anc, b->big, list);
+    int64_t gx = ceil_div(slot_hi - slot_lo, (int64_t)TPB * 8);
+    gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+    k_scatter_big<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(b->big, list, b->slot0, b->anc);
+    HIPCHECK(hipGetLastError());
+    return EPI_OK;
+}
+
 int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
 {
     int rc = belief_check(b, "epi_pf_update");
@@ -1576,9 +1653,8 @@ int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t
     if (rc) return rc;
     k_scal_total_local<<<1, 1, 0, c->stream>>>(c->d_scal);
     const double u = resample_offset(seed, step);
-    k_select<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, 0, 0, reinterpret_cast<const unsigned long long*>(b->lw),
-                                                                              b->n, c->d_scal, b->n_total, u, b->anc);
-    HIPCHECK(hipGetLastError());
+    rc = launch_scatter(c, b, u, 0, b->n);
+    if (rc) return rc;
     b->cur ^= 1; b->has_anc = true;
     return EPI_OK;
 }
@@ -1745,9 +1821,8 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
     if (rc) return rc;
     const double u = resample_offset(seed, step);
     const int64_t count = slot_end - slot_begin;
-    k_select<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin, b->slot0, reinterpret_cast<const unsigned long long*>(b->lw),
-                                                                             b->n, c->d_scal, b->n_total, u, b->anc);
-    HIPCHECK(hipGetLastError());
+    rc = launch_scatter(c, b, u, slot_begin, slot_end);
+    if (rc) return rc;
     return EPI_OK;
 }
 
