@@ -79,6 +79,7 @@ struct epi_ctx {
     bool have_params = false;
     DevScalars* d_scal = nullptr;
     DevParams* d_params = nullptr;      // parameters + derived per-bin constants, as the kernels read them
+    double* d_lf = nullptr;             // lfact(k), k < LF_TABLE_N
     long long* d_sums = nullptr;        // 2 + H + (D+1) H column sums
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -109,6 +110,7 @@ struct epi_belief {
 };
 
 static const int TPB = 256;            // threads per workgroup
+static const int LF_TABLE_N = 1 << 20; // tabulated log factorials (8 MB per context); larger arguments are computed
 static const int SCAN_ITEMS = 8;       // fixed-point weights per thread in the scan kernels
 static const int SCAN_TILE = TPB * SCAN_ITEMS;
 
@@ -295,7 +297,8 @@ __device__ __forceinline__ void q_push2(bool want0, bool want1, unsigned short e
 }
 
 #ifndef EPI_COOP_WAVES
-#define EPI_COOP_WAVES 3   // waves per SIMD the register allocation aims at: 168 VGPRs; 4 spills, 2 starves the issue slots
+#define EPI_COOP_WAVES 4   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
+                           // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 #endif
 template <bool WEIGH>
 __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 bool fail = false;
                 if (cls == BINOM_INVERSION) x = binom_inversion(n, Dp->lnq[j][i], Dp->sr[j][i], wa);
                 else if (cls == BINOM_REJECTION) {
-                    const BtrsConsts C = btrs_consts(n, pp, screen);
+                    const BtrsConsts C = btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen);
                     x = btrs_attempt(C, wa, wb);
                     fail = x < 0;
                 }
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                     const int32_t n = j ? nn.y : nn.x;
                     int32_t x; double pp; bool flip;
                     binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
-                    const int32_t k = btrs_finish(btrs_consts(n, pp, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
+                    const int32_t k = btrs_finish(btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
                     slot_words[(i * TPB + tid) * 2 + j] = flip ? n - k : k;
                 }
             }
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 const int32_t n = slot_words[(i * TPB + t) * 2 + j];
                 int32_t x; double pp; bool flip;
                 binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
-                const BtrsConsts C = btrs_consts(n, pp, screen);
+                const BtrsConsts C = btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wa, wb;
                 retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
@@ -888,18 +891,24 @@ __global__ __launch_bounds__(TPB) void k_sums(int64_t n, const int32_t* __restri
     }
 }
 
+__global__ __launch_bounds__(TPB) void k_lfact_fill(double* __restrict__ t, int n)
+{
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k < n) t[k] = lfact((double)k);
+}
+
 // ---------------------------------------------------------------------------
 // bare samplers (element j draws from the streams of slot j)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_sample_binomial(int64_t count, const int32_t* __restrict__ n, const double* __restrict__ p,
-                                                          uint64_t seed, uint32_t step, uint32_t bin, int which, int32_t* __restrict__ out, bool screen)
+                                                          uint64_t seed, uint32_t step, uint32_t bin, int which, int32_t* __restrict__ out, bool screen, LfTable lf)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= count) return;
     Rng g = rng_make(seed, (uint64_t)j, step);
     uint32_t w[4];
     rng_block(g, K_BINOM0, bin, 0, w);
-    out[j] = which ? binomial_draw(n[j], p[j], w[2], w[3], g, K_POS, bin) : binomial_draw(n[j], p[j], w[0], w[1], g, K_SYMPT, bin);
+    out[j] = which ? binomial_draw(n[j], p[j], w[2], w[3], g, K_POS, bin, lf, screen) : binomial_draw(n[j], p[j], w[0], w[1], g, K_SYMPT, bin, lf, screen);
 }
 
 __global__ __launch_bounds__(TPB) void k_sample_gamma(int64_t count, const double* __restrict__ shape, const double* __restrict__ scale,
@@ -1012,6 +1021,10 @@ int epi_ctx_create(int device, epi_ctx** out)
     HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
     HIPCHECK(hipMemset(c->d_scal, 0, 256));
     HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
+    HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
+    k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(c->stream));
     HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
     HIPCHECK(hipEventCreate(&c->ev0));
     HIPCHECK(hipEventCreate(&c->ev1));
@@ -1029,6 +1042,7 @@ int epi_ctx_destroy(epi_ctx* c)
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->d_sums) (void)hipFree(c->d_sums);
     if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_lf) (void)hipFree(c->d_lf);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return EPI_OK;
@@ -1053,6 +1067,7 @@ int epi_params_set(epi_ctx* c, const epi_params* p)
     memset(&dp, 0, sizeof dp);
     dp.P = *p;
     derive_params(dp);
+    dp.lf = LfTable{c->d_lf, LF_TABLE_N};
     HIPCHECK(hipMemcpy(c->d_params, &dp, sizeof dp, hipMemcpyHostToDevice));
     c->P = *p;
     c->have_params = true;
@@ -1447,7 +1462,7 @@ int epi_sample_binomial(epi_ctx* c, int64_t count, const int64_t* n, const doubl
         return fail(EPI_ENOMEM, "epi_sample_binomial: hipMalloc failed");
     HIPCHECK(hipMemcpyAsync(dn.p, hn.data(), 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(dp.p, p, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>(), g_screen != 0);
+    k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>(), g_screen != 0, LfTable{c->d_lf, LF_TABLE_N});
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(hn.data(), dout.p, 4 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));

@@ -202,73 +202,54 @@ constexpr uint32_t BINOM_MAX_ATTEMPTS = 512u;
 // ---- single-precision screens (device only) ---------------------------------------
 // The accept/reject decisions of the two rejection samplers are DEFINED by the
 // binary64 expressions in binomial_draw / gamma_draw below.  On the device most
-// of those evaluations are avoided: the same quantity is first estimated in
-// binary32 with the hardware reciprocal / log2 approximations, in a form without
-// cancellation, and the estimate decides whenever it is further from the
-// threshold than a guard band many times its error bound.  Only draws inside the
-// band fall through to the defining binary64 expression, so results are
-// unchanged bit for bit.
+// of the logarithms are avoided: the quantity is first estimated in binary32 with
+// the hardware reciprocal / log2 approximations, and the estimate decides whenever
+// it is further from the threshold than a guard band many times its error bound.
+// Only draws inside the band fall through to the defining binary64 expression, so
+// results are unchanged bit for bit.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EPI_HAVE_SCREEN 1
 __device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float f_ln(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
+#endif
 
-// log1p(t) - t for t > -1: series below 1/8, hardware log above
-__device__ __forceinline__ float f_log1p_minus(float t)
+// log(k!) for an integer k >= 0 held in a double: Stirling's formula with the tail above, evaluated
+// left to right as written.  (Absolute error a few ulp of the value; differences of four of them
+// are what the acceptance test below uses.)
+EPI_HD double lfact(double k)
 {
-    float p = 0.111111111f;
-    p = __builtin_fmaf(p, t, -0.125f);
-    p = __builtin_fmaf(p, t, 0.142857143f);
-    p = __builtin_fmaf(p, t, -0.166666667f);
-    p = __builtin_fmaf(p, t, 0.2f);
-    p = __builtin_fmaf(p, t, -0.25f);
-    p = __builtin_fmaf(p, t, 0.333333333f);
-    p = __builtin_fmaf(p, t, -0.5f);
-    float ser = (t * t) * p;
-    float big = f_ln(1.0f + t) - t;
-    return __builtin_fabsf(t) <= 0.125f ? ser : big;
+    return ((k + 0.5) * s_log(k + 1.0) - (k + 1.0)) + 0.91893853320467274178 + stirling_tail(k);
 }
 
-// Stirling tail for k >= 2 (argument k + 1 >= 3), error < 3e-7
-__device__ __forceinline__ float f_stirling_tail(float kp1)
+// The same values tabulated for k < n (device memory, filled by evaluating lfact on the device), so that
+// the acceptance test costs four loads instead of four logarithms; larger k are computed.
+struct LfTable {
+    const double* t;
+    int32_t n;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__ double lfact_far(double k) { return lfact(k); }
+__device__ __forceinline__ double lfact_of(const LfTable& T, double k)
 {
-    float r = f_rcp(kp1), r2 = r * r;
-    return r * __builtin_fmaf(r2, __builtin_fmaf(r2, 7.93650794e-4f, -2.77777778e-3f), 8.33333333e-2f);
+    if (k < (double)T.n) return T.t[(int32_t)k];
+    return lfact_far(k);
 }
+#else
+static inline double lfact_of(const LfTable&, double k) { return lfact(k); }
 #endif
 
 // The defining acceptance test of the transformed-rejection sampler (Hoermann 1993, step 3):
-// log(v alpha / (a/us^2 + b)) <= log f(k) - log f(m), with Stirling-corrected log factorials.
-// (out of line on the device: it runs for a few draws in ten thousand, and inlined its four logarithms set the
-// register allocation of every kernel that samples a binomial)
+//   log(v alpha / (a/us^2 + b))  <=  log f(k) - log f(m)
+//                                 =  [lfact(m) + lfact(n-m)] - [lfact(k) + lfact(n-k)] + (k - m) log(p/q).
+// btrs_lv is the left side (out of line on the device: it runs for a few attempts in a hundred thousand).
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __noinline__
 #else
 static inline
 #endif
-bool btrs_accept_exact(double nd, double pp, double qq, double m, double kd, double v, double us, double a, double b, double alpha)
+double btrs_lv(double v, double us, double a, double b, double alpha)
 {
-    const double r = pp / qq;
-    const double lv = s_log(v * alpha / (a / (us * us) + b));
-    const double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
-                    + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
-                    + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
-                    + stirling_tail(m) + stirling_tail(nd - m)
-                    - stirling_tail(kd) - stirling_tail(nd - kd);
-    return lv <= ub;
-}
-
-// lv - ub of the same test in binary64 (measurement of the screens' error only)
-EPI_HD double btrs_exact_diff(double nd, double pp, double qq, double m, double kd, double v, double us, double a, double b, double alpha)
-{
-    const double r = pp / qq;
-    const double lv = s_log(v * alpha / (a / (us * us) + b));
-    const double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
-                    + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
-                    + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
-                    + stirling_tail(m) + stirling_tail(nd - m)
-                    - stirling_tail(kd) - stirling_tail(nd - kd);
-    return lv - ub;
+    return s_log(v * alpha / (a / (us * us) + b));
 }
 
 // A Binomial(n, p) draw is split into pieces so that a kernel can either loop over attempts
@@ -335,40 +316,31 @@ EPI_HD int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
 }
 
 struct BtrsConsts {
-    double nd, pp, qq, a, b, c, vr, alpha, m;
+    double nd, pp, a, b, c, vr, alpha, m, lpq;
+    LfTable lf;
 #ifdef EPI_HAVE_SCREEN
-    // constants of the binary32 screens.  With m1 = m+1, n1 = n-m+1, dk = k-m:
-    //   ub = -dk LA - dk(dk+1/2)/n1 - dk(dk-1/2)/m1 - (n-k+1/2) g(-dk/n1) - (k+1/2) g(dk/m1)
-    //        + fc(m) + fc(n-m) - fc(k) - fc(n-k),      g(t) = log1p(t) - t,
-    //   LA = log((m+1) q / (p n1)) = log1p((1 - frac((n+1)p) - p) / (p n1))
-    // which is the defining expression (btrs_accept_exact) rearranged so that no large terms cancel.
-    double cfl;
-    float m1f, n1f, rm1, rn1, LA, fcm, af, bf, alf, cfr;
+    double cfl;                     // floor(c), and below its fraction: the k estimate works on small numbers
+    float af, bf, alf, cfr;
     bool scr;
 #endif
 };
 
-EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, bool screen)
+// lpq = s_log(pp / (1 - pp)) (a per-probability constant, tabulated per age bin by the kernels)
+EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, double lpq, const LfTable& lf, bool screen)
 {
     BtrsConsts C;
-    C.nd = (double)n; C.pp = pp; C.qq = 1.0 - pp;
+    C.nd = (double)n; C.pp = pp; C.lpq = lpq; C.lf = lf;
     // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
-    const double spq = (double)__builtin_sqrtf((float)(C.nd * pp * C.qq));
+    const double spq = (double)__builtin_sqrtf((float)(C.nd * pp * (1.0 - pp)));
     C.b = 1.15 + 2.53 * spq;
     C.a = -0.0873 + 0.0248 * C.b + 0.01 * pp;
     C.c = C.nd * pp + 0.5;
     const double ib = (double)(1.0f / (float)C.b);
     C.vr = 0.92 - 4.2 * ib;
     C.alpha = (2.83 + 5.1 * ib) * spq;
-    const double mt = (C.nd + 1.0) * pp;
-    C.m = __builtin_floor(mt);
+    C.m = __builtin_floor((C.nd + 1.0) * pp);
 #ifdef EPI_HAVE_SCREEN
-    C.scr = screen && C.nd < 16777216.0;
-    C.m1f = (float)(C.m + 1.0); C.n1f = (float)(C.nd - C.m + 1.0);
-    C.rm1 = f_rcp(C.m1f); C.rn1 = f_rcp(C.n1f);
-    const float dA = (float)(1.0 - (mt - C.m) - pp) * f_rcp((float)pp * C.n1f);
-    C.LA = dA + f_log1p_minus(dA);
-    C.fcm = f_stirling_tail(C.m1f) + f_stirling_tail(C.n1f);
+    C.scr = screen;
     C.af = (float)C.a; C.bf = (float)C.b; C.alf = (float)C.alpha;
     C.cfl = __builtin_floor(C.c);
     C.cfr = (float)(C.c - C.cfl);
@@ -379,26 +351,22 @@ EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, bool screen)
 }
 
 #ifdef EPI_HAVE_SCREEN
-// binary32 estimate of lv - ub of the acceptance test (accept iff lv <= ub) and the sum `mag` of the magnitudes
-// of its terms.  Rounding analysis (unit roundoff 6e-8, rcp / log2 within 1 ulp, Stirling tails within 3e-7):
-// |estimate - exact| < 1.5e-6 mag + 2e-6.  Measured over 2e9 undecided attempts (n from 20 to 1.6e7, p from 3e-6
-// to 0.9999; tools/ubench.hip): never above 3e-6 mag + 1e-5.  The guard band is four times the measured worst case.
-constexpr float BTRS_GUARD_REL = 1.2e-5f, BTRS_GUARD_ABS = 4e-5f;
-__device__ __forceinline__ float btrs_screen(const BtrsConsts& C, double kd, double us, double v, float& mag)
+// Guard band of the binary32 estimate of btrs_lv: its argument carries a relative error below 12 roundings
+// (7e-7), the hardware log2 one ulp of its result, so |estimate - exact| < 1e-6 + 3e-7 |lv|; the band is ten
+// times that (tools/ubench.hip measures the actual worst case).
+constexpr float BTRS_GUARD_REL = 3e-6f, BTRS_GUARD_ABS = 1e-5f;
+__device__ __forceinline__ float btrs_lv_screen(const BtrsConsts& C, double us, double v)
 {
-    const float dk = (float)(kd - C.m);
-    const float k1f = C.m1f + dk, nk1f = C.n1f - dk;
     const float usf = (float)us;
-    const float lv = f_ln((float)v * C.alf * f_rcp(__builtin_fmaf(C.af, f_rcp(usf * usf), C.bf)));
-    const float t_a = dk * C.LA;
-    const float t_l1 = dk * (dk + 0.5f) * C.rn1, t_l2 = dk * (dk - 0.5f) * C.rm1;
-    const float t_g1 = (nk1f - 0.5f) * f_log1p_minus(-dk * C.rn1), t_g2 = (k1f - 0.5f) * f_log1p_minus(dk * C.rm1);
-    const float t_fc = f_stirling_tail(k1f) + f_stirling_tail(nk1f);
-    const float ub = C.fcm - t_fc - t_a - t_l1 - t_l2 - t_g1 - t_g2;
-    mag = __builtin_fabsf(lv) + __builtin_fabsf(t_a) + t_l1 + t_l2 - t_g1 - t_g2 + C.fcm + t_fc;
-    return lv - ub;
+    return f_ln((float)v * C.alf * f_rcp(__builtin_fmaf(C.af, f_rcp(usf * usf), C.bf)));
 }
 #endif
+
+// right side of the acceptance test for an in-range k
+EPI_HD double btrs_ub(const BtrsConsts& C, double kd)
+{
+    return ((lfact_of(C.lf, C.m) + lfact_of(C.lf, C.nd - C.m)) - (lfact_of(C.lf, kd) + lfact_of(C.lf, C.nd - kd))) + (kd - C.m) * C.lpq;
+}
 
 // k = floor((2a/us + b) u + c) of one attempt
 EPI_HD double btrs_k(const BtrsConsts& C, double u, double us)
@@ -429,16 +397,17 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
     const double kd = btrs_k(C, u, us);
     if (kd < 0.0 || kd > C.nd) return -1;
     if (us >= 0.07 && v <= C.vr) return (int32_t)kd;
+    const double ub = btrs_ub(C, kd);
 #ifdef EPI_HAVE_SCREEN
-    if (C.scr && kd >= 2.0 && C.nd - kd >= 2.0) {
-        float mag;
-        const float diff = btrs_screen(C, kd, us, v, mag);
-        const float guard = __builtin_fmaf(mag, BTRS_GUARD_REL, BTRS_GUARD_ABS);
+    if (C.scr) {
+        const float lvf = btrs_lv_screen(C, us, v);
+        const double diff = (double)lvf - ub;
+        const double guard = (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS);
         if (diff < -guard) return (int32_t)kd;
         if (diff > guard) return -1;
     }
 #endif
-    return btrs_accept_exact(C.nd, C.pp, C.qq, C.m, kd, v, us, C.a, C.b, C.alpha) ? (int32_t)kd : -1;
+    return btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? (int32_t)kd : -1;
 }
 
 // Word pair of attempt `att` (>= 1) of a retry stream: block (att-1)/2, words (0,1) or (2,3).
@@ -469,14 +438,14 @@ EPI_HD int32_t btrs_finish(const BtrsConsts& C, const Rng& g, uint32_t kind, uin
 // fa, fb: the attempt-0 word pair; attempts a >= 1 come from blocks of retry_kind.
 // screen: allow the binary32 screens (device only; never changes the result).
 EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
-                             const Rng& g, uint32_t retry_kind, uint32_t bin, bool screen = true)
+                             const Rng& g, uint32_t retry_kind, uint32_t bin, const LfTable& lf, bool screen = true)
 {
     int32_t x; double pp; bool flip;
     const int cls = binom_classify(n, p, x, pp, flip);
     if (cls == BINOM_DONE) return x;
     if (cls == BINOM_INVERSION) x = binom_inversion(n, s_log(1.0 - pp), pp / (1.0 - pp), fa);
     else {
-        const BtrsConsts C = btrs_consts(n, pp, screen);
+        const BtrsConsts C = btrs_consts(n, pp, s_log(pp / (1.0 - pp)), lf, screen);
         x = btrs_attempt(C, fa, fb);
         if (x < 0) x = btrs_finish(C, g, retry_kind, bin, 1u);
     }

@@ -40,6 +40,8 @@ struct DevParams {
     epi_params P;
     double lnq[2][EPI_MAX_H];   // s_log(1 - pp), pp = min(p, 1 - p)
     double sr[2][EPI_MAX_H];    // pp / (1 - pp)
+    double lpq[2][EPI_MAX_H];   // s_log(pp / (1 - pp))
+    LfTable lf;                 // tabulated log factorials (device memory; null on the host)
 };
 
 __host__ __device__ inline void derive_params(DevParams& D)
@@ -51,6 +53,7 @@ __host__ __device__ inline void derive_params(DevParams& D)
             const bool ok = pp > 0.0 && pp < 1.0;
             D.lnq[j][i] = ok ? s_log(1.0 - pp) : 0.0;
             D.sr[j][i] = ok ? pp / (1.0 - pp) : 0.0;
+            D.lpq[j][i] = ok ? s_log(pp / (1.0 - pp)) : 0.0;
         }
 }
 
@@ -63,7 +66,7 @@ __device__ __forceinline__ int32_t bin_binomial(const DevParams& D, int bin, int
     if (cls == BINOM_DONE) return x;
     if (cls == BINOM_INVERSION) x = binom_inversion(n, D.lnq[j][bin], D.sr[j][bin], fa);
     else {
-        const BtrsConsts C = btrs_consts(n, pp, screen);
+        const BtrsConsts C = btrs_consts(n, pp, D.lpq[j][bin], D.lf, screen);
         x = btrs_attempt(C, fa, fb);
         if (x < 0) x = btrs_finish(C, g, j ? K_POS : K_SYMPT, (uint32_t)bin, 1u);
     }

@@ -259,6 +259,12 @@ static inline double stirling_tail(double k)
     return (0.08333333333333333 - (0.002777777777777778 - 0.0007936507936507937 * r2) * r2) * r;
 }
 
+/* log(k!) for an integer k >= 0 held in a double: Stirling's formula with the tail above, left to right */
+static inline double lfact(double k)
+{
+    return ((k + 0.5) * s_log(k + 1.0) - (k + 1.0)) + 0.91893853320467274178 + stirling_tail(k);
+}
+
 typedef struct {
     const rng_t *g;
     uint32_t bin;
@@ -318,7 +324,7 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
         double ib = (double)(1.0f / (float)b);
         double vr = 0.92 - 4.2 * ib;
         double alpha = (2.83 + 5.1 * ib) * spq;
-        double r = pp / qq;
+        double lpq = s_log(pp / qq);
         double m = floor((nd + 1.0) * pp);
         x = (int64_t)m;                         /* returned only if every attempt fails */
         for (uint32_t att = 0; att < BINOM_MAX_ATTEMPTS; att++) {
@@ -330,12 +336,9 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
             double kd = floor((2.0 * a / us + b) * u + c);
             if (kd < 0.0 || kd > nd) continue;
             if (us >= 0.07 && v <= vr) { x = (int64_t)kd; break; }
+            /* log(v alpha / (a/us^2 + b)) <= log f(k) - log f(m), the pmf ratio from log factorials */
             double lv = s_log(v * alpha / (a / (us * us) + b));
-            double ub = (m + 0.5) * s_log((m + 1.0) / (r * (nd - m + 1.0)))
-                      + (nd + 1.0) * s_log((nd - m + 1.0) / (nd - kd + 1.0))
-                      + (kd + 0.5) * s_log(r * (nd - kd + 1.0) / (kd + 1.0))
-                      + stirling_tail(m) + stirling_tail(nd - m)
-                      - stirling_tail(kd) - stirling_tail(nd - kd);
+            double ub = ((lfact(m) + lfact(nd - m)) - (lfact(kd) + lfact(nd - kd))) + (kd - m) * lpq;
             if (lv <= ub) { x = (int64_t)kd; break; }
         }
     }

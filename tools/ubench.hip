@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_binom(uint64_t seed, const int32_t* nn,
     int32_t acc = 0, nv = nn[i];
     for (int r = 0; r < REP; r++) {
         uint32_t w[4]; rng_block(g, K_BINOM0, r, 0, w);
-        acc += binomial_draw(nv, p, w[0], w[1], g, K_SYMPT, r);
+        acc += binomial_draw(nv, p, w[0], w[1], g, K_SYMPT, r, LfTable{nullptr, 0});
     }
     out[i] = acc;
 }
@@ -123,18 +123,19 @@ __global__ __launch_bounds__(256) void k_btrs_screen_err(uint64_t seed, int32_t 
     int32_t x; double pp; bool flip;
     float worst = 0.f; unsigned int seen = 0, band = 0;
     if (binom_classify(n, p, x, pp, flip) == BINOM_REJECTION) {
-        const BtrsConsts C = btrs_consts(n, pp, true);
+        const BtrsConsts C = btrs_consts(n, pp, s_log(pp / (1.0 - pp)), LfTable{nullptr, 0}, true);
         for (uint32_t r = 0; r < 64; r++) {
             uint32_t w[4]; rng_block(g, 1, r, 0, w);
             for (int half = 0; half < 2; half++) {
                 const double u = u01(w[2 * half]) - 0.5, v = u01(w[2 * half + 1]), us = 0.5 - __builtin_fabs(u);
                 const double kd = btrs_k(C, u, us);
-                if (kd < 0.0 || kd > C.nd || (us >= 0.07 && v <= C.vr) || !(C.scr && kd >= 2.0 && C.nd - kd >= 2.0)) continue;
-                float mag;
-                const float d32 = btrs_screen(C, kd, us, v, mag);
-                const double d64 = btrs_exact_diff(C.nd, C.pp, C.qq, C.m, kd, v, us, C.a, C.b, C.alpha);
-                const float guard = __builtin_fmaf(mag, BTRS_GUARD_REL, BTRS_GUARD_ABS);
-                const float ratio = (float)__builtin_fabs((double)d32 - d64) / guard;
+                if (kd < 0.0 || kd > C.nd || (us >= 0.07 && v <= C.vr)) continue;
+                const float lvf = btrs_lv_screen(C, us, v);
+                const double lv = btrs_lv(v, us, C.a, C.b, C.alpha);
+                const double ub = btrs_ub(C, kd);
+                const float guard = __builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS);
+                const float ratio = (float)__builtin_fabs((double)lvf - lv) / guard;
+                const float d32 = (float)((double)lvf - ub);
                 worst = ratio > worst ? ratio : worst;
                 seen++; band += __builtin_fabsf(d32) <= guard;
             }
