@@ -272,30 +272,6 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
     return true;
 }
 
-// the same for up to two entries per lane (entry e0 if want0, e1 if want1) with one atomic per wave;
-// ok0 / ok1 = false where the entry did not fit
-__device__ __forceinline__ void q_push2(bool want0, bool want1, unsigned short e0, unsigned short e1, unsigned short* q, unsigned int* qn,
-                                        bool& ok0, bool& ok1)
-{
-    ok0 = true; ok1 = true;
-    const unsigned long long m0 = __ballot(want0), m1 = __ballot(want1);
-    if ((m0 | m1) == 0ULL) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned int c0 = (unsigned int)__popcll(m0), c1 = (unsigned int)__popcll(m1);
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(qn, c0 + c1);
-    base = __shfl(base, 0, 64);
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    if (want0) {
-        const unsigned int pos = base + (unsigned int)__popcll(m0 & below);
-        if (pos < QCAP) q[pos] = e0; else ok0 = false;
-    }
-    if (want1) {
-        const unsigned int pos = base + c0 + (unsigned int)__popcll(m1 & below);
-        if (pos < QCAP) q[pos] = e1; else ok1 = false;
-    }
-}
-
 #ifndef EPI_COOP_WAVES
 #define EPI_COOP_WAVES 4   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
                            // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
@@ -304,6 +280,10 @@ template <bool WEIGH>
 __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
+    // Arguments needed only at the end of the kernel are re-read from the kernel-argument segment there (scalar
+    // loads) instead of occupying scalar registers across the sampler phases, which are short of them.
+    typedef const StepArgs __attribute__((address_space(4)))* KernArgs;
+    const KernArgs Ak = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = P.H, D = P.D;
     int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][TPB]: (I_i, tested_i) -> (sympt_i, pos_i)
@@ -364,13 +344,16 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
     __syncthreads();
 
     // ---- B: attempt 0 of both binomials of every bin --------------------------------
+    // rejected draws are remembered in a bit mask (bit 2 i + j) and queued in one go after the loop: one
+    // prefix sum and one LDS atomic per wave instead of one per bin
+    unsigned long long fm0 = 0ULL, fm1 = 0ULL;                                     // bins 0..31 / 32..63
 #pragma unroll 1
     for (int i = 0; i < H; i++) {
-        bool fail0 = false, fail1 = false;
         if (active) {
             int2 nn = slots[i * TPB + tid];
             uint32_t w[4];
             rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
+            unsigned int failbits = 0u;
 #pragma unroll 1
             for (int j = 0; j < 2; j++) {
                 const int32_t n = j ? nn.y : nn.x;
@@ -385,23 +368,43 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                     fail = x < 0;
                 }
                 const int32_t res = fail ? n : (flip ? n - x : x);                 // a rejected draw keeps n for its retry
-                if (j) { nn.y = res; fail1 = fail; } else { nn.x = res; fail0 = fail; }
+                if (j) nn.y = res; else nn.x = res;
+                failbits |= (unsigned int)fail << j;
             }
             slots[i * TPB + tid] = nn;
+            if (i < 32) fm0 |= (unsigned long long)failbits << (2 * i);
+            else fm1 |= (unsigned long long)failbits << (2 * (i - 32));
         }
-        const unsigned short e0 = (unsigned short)(tid | (i << 8));
-        bool ok0, ok1;
-        q_push2(fail0, fail1, e0, (unsigned short)(e0 | (1 << 14)), q0, &qn[0], ok0, ok1);
-        if ((fail0 && !ok0) || (fail1 && !ok1)) {                                  // queue full: finish here
-            int2 nn = slots[i * TPB + tid];
-            for (int j = 0; j < 2; j++) {
-                if (j ? (fail1 && !ok1) : (fail0 && !ok0)) {
-                    const int32_t n = j ? nn.y : nn.x;
+    }
+    {
+        const int lane = tid & 63;
+        const unsigned int mine = (unsigned int)(__popcll(fm0) + __popcll(fm1));
+        unsigned int incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        const unsigned int total = __shfl(incl, 63, 64);
+        unsigned int pos = 0u;
+        if (total) {                                                                // wave-uniform
+            if (lane == 63) pos = atomicAdd(&qn[0], total);
+            pos = __shfl(pos, 63, 64) + incl - mine;
+        }
+        for (int half = 0; half < 2; half++) {
+            unsigned long long fm = half ? fm1 : fm0;
+            while (fm) {
+                const int bit = __ffsll((long long)fm) - 1;
+                fm &= fm - 1ULL;
+                const int i = (bit >> 1) + 32 * half, j = bit & 1;
+                if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14));
+                else {                                                              // queue full: finish here
+                    const int32_t n = slot_words[(i * TPB + tid) * 2 + j];
                     int32_t x; double pp; bool flip;
                     binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
                     const int32_t k = btrs_finish(btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
                     slot_words[(i * TPB + tid) * 2 + j] = flip ? n - k : k;
                 }
+                pos++;
             }
         }
     }
@@ -544,17 +547,22 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         out[(int64_t)2 * os + m] = newi;                                                        // simulate.jl:147
         out[m] = S - newi;                                                                      // simulate.jl:148
         out[os + m] = R;
-        if (A.o_out) A.o_out[m] = o_sum;
-        if (A.newinf_out) A.newinf_out[m] = newi;
-        if (A.r_out) {
-            const double ap = A.a_prev_dev ? A.a_prev_dev[arow * A.a_row_stride + A.a_prev_col] : A.a_prev;
-            A.r_out[m] = reward_of(P, sum_inf + newi, a, ap);
+        if (Ak->o_out) Ak->o_out[m] = o_sum;
+        if (Ak->newinf_out) Ak->newinf_out[m] = newi;
+        if (Ak->r_out) {
+            const int64_t prow = Ak->a_div > 1 ? m / Ak->a_div : m;
+            const double ap = Ak->a_prev_dev ? Ak->a_prev_dev[prow * Ak->a_row_stride + Ak->a_prev_col] : Ak->a_prev;
+            Ak->r_out[m] = reward_of(P, sum_inf + newi, a, ap);
         }
-        if (A.hist) { A.hist[m] = S; A.hist[A.n + m] = suminf_pre; A.hist[2 * A.n + m] = R_pre; A.hist[3 * A.n + m] = o_sum; }
+        if (Ak->hist) {
+            int32_t* hist = Ak->hist;
+            const int64_t hn = Ak->n;
+            hist[m] = S; hist[hn + m] = suminf_pre; hist[2 * hn + m] = R_pre; hist[3 * hn + m] = o_sum;
+        }
     }
     unsigned int wf = flags;
     for (int d = 32; d >= 1; d >>= 1) wf |= __shfl_down(wf, d, 64);
-    if ((tid & 63) == 0 && wf) atomicOr(&A.scal->flags, wf);
+    if ((tid & 63) == 0 && wf) atomicOr(&Ak->scal->flags, wf);
     if constexpr (WEIGH) {
         for (int d = 32; d >= 1; d >>= 1) {
             unsigned long long o = shfl_down_u64(code, d);
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         if (tid == 0) {
             unsigned long long c = s_max[0];
             for (int w = 1; w < TPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
-            atomicMax(&A.scal->lwmax_bits, c);
+            atomicMax(&Ak->scal->lwmax_bits, c);
         }
     }
 }
