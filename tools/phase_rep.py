@@ -72,7 +72,23 @@ def phase_E(s):
     return s
 
 
-PH = {"A": phase_A, "B": phase_B, "C": phase_C, "D": phase_D, "E": phase_E}
+def phase_G(s):
+    """only the gamma part of phase D (normals, constants, attempt 0, scaling)"""
+    s = sub(s, '            const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78\n',
+            '            ' + REP + '            const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78\n')
+    s = sub(s, '                else { slots[i * TPB + tid] = make_int2(Ii, 0); gfail = true; }\n            }\n',
+            '                else { slots[i * TPB + tid] = make_int2(Ii, 0); gfail = true; }\n            }\n            }\n')
+    return s
+
+
+def phase_P(s):
+    """only the Philox block of phase B"""
+    s = sub(s, '            rng_block(g, K_BINOM0, (uint32_t)i, 0, w);\n',
+            '            for (int rep = 0; rep < reps; rep++) rng_block(g, K_BINOM0, (uint32_t)i + (uint32_t)rep * 0u, 0, w);\n')
+    return s
+
+
+PH = {"G": phase_G, "P": phase_P, "A": phase_A, "B": phase_B, "C": phase_C, "D": phase_D, "E": phase_E}
 which = sys.argv[1:] or list(PH)
 flags = "-O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math --offload-arch=gfx950".split()
 procs = []
