@@ -365,6 +365,13 @@ __device__ __forceinline__ float btrs_lv_screen(const BtrsConsts& C, double us, 
 // right side of the acceptance test for an in-range k
 EPI_HD double btrs_ub(const BtrsConsts& C, double kd)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (C.nd < (double)C.lf.n) {            // every argument is inside the table: four loads, no branches
+        const double* __restrict__ t = C.lf.t;
+        const int32_t ni = (int32_t)C.nd, mi = (int32_t)C.m, ki = (int32_t)kd;
+        return ((t[mi] + t[ni - mi]) - (t[ki] + t[ni - ki])) + (kd - C.m) * C.lpq;
+    }
+#endif
     return ((lfact_of(C.lf, C.m) + lfact_of(C.lf, C.nd - C.m)) - (lfact_of(C.lf, kd) + lfact_of(C.lf, C.nd - kd))) + (kd - C.m) * C.lpq;
 }
 
