@@ -27,6 +27,12 @@ constexpr uint32_t K_RESAMP = 5u;  // slot 0: words 0,1 -> 53-bit systematic-res
 constexpr uint32_t K_INIT   = 6u;  // initial-state generators
 
 #define EPI_HD __host__ __device__ __forceinline__
+// rarely executed pieces are kept out of line on the device, where inlining them costs the callers registers
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EPI_HD_OUTLINE __host__ __device__ __noinline__
+#else
+#define EPI_HD_OUTLINE __host__ __device__ inline
+#endif
 
 EPI_HD uint64_t d2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 EPI_HD double u2d(uint64_t u) { return __builtin_bit_cast(double, u); }
@@ -281,8 +287,10 @@ static
 const double EPI_RECIP[72] = { 0.0, EPI_R(1), EPI_R(2), EPI_R(3), EPI_R(4), EPI_R(5), EPI_R(6), EPI_R(7),
     EPI_R8(8), EPI_R8(16), EPI_R8(24), EPI_R8(32), EPI_R8(40), EPI_R8(48), EPI_R8(56), EPI_R8(64) };
 
-// lnq = s_log(1 - pp), s = pp / (1 - pp): per-probability constants, tabulated per age bin by the kernels
-EPI_HD int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
+// lnq = s_log(1 - pp), s = pp / (1 - pp): per-probability constants, tabulated per age bin by the kernels.
+// (Out of line on the device: inlined into a loop over bins, the constants of its exponential are hoisted
+// into vector registers that the loop's common path then lacks.)
+EPI_HD_OUTLINE int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
 {
     const double nd = (double)n;
     const double a1 = nd + 1.0;
@@ -538,14 +546,18 @@ EPI_HD bool gamma_attempt(const GammaConsts& G, float xf, uint32_t wu, double& v
     return s_log(u) < 0.5 * x2 + G.d * (1.0 - vv + s_log(vv));
 }
 
+// U^(1/shape) of the boost for shape < 1 (out of line on the device, for the same reason as binom_inversion)
+EPI_HD_OUTLINE double gamma_boost(double shape, const Rng& g, uint32_t bin)
+{
+    uint32_t wb[4];
+    rng_block(g, K_BOOST, bin, 0, wb);
+    return s_exp(s_log(u01(wb[0])) / shape);
+}
+
 EPI_HD double gamma_finish(const GammaConsts& G, double v, double scale, const Rng& g, uint32_t bin)
 {
     double gval = G.d * v;
-    if (G.boost) {
-        uint32_t wb[4];
-        rng_block(g, K_BOOST, bin, 0, wb);
-        gval = gval * s_exp(s_log(u01(wb[0])) / G.shape);
-    }
+    if (G.boost) gval = gval * gamma_boost(G.shape, g, bin);
     return gval * scale;
 }
 
