@@ -77,6 +77,9 @@ SIGNATURES = {
     "epi_pf_frac_bits": (C.c_int, [C.c_int64]),
     "epi_pf_predict": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p]),
     "epi_pf_weigh": (C.c_int, [_vp, _vp, C.c_double, _u64p, _f64p, _u32p]),
+    "epi_pf_predict_dev": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _vp]),
+    "epi_pf_weigh_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "epi_ctx_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "epi_pf_plan": (C.c_int, [C.c_int64, C.c_int, _u64p, C.c_uint64, C.c_uint32, _i64p]),
     "epi_pf_select_local": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _u64p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64]),
     "epi_pf_export": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _u64p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, _vp]),

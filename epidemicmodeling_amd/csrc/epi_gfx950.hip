@@ -75,6 +75,8 @@ struct DevScalars {
 struct epi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;   // created with the context; `stream` is this one unless a caller's was adopted
+    bool external = false;              // stream adopted from the caller: the phased update then never blocks the host
     epi_params P;
     bool have_params = false;
     DevScalars* d_scal = nullptr;
@@ -616,6 +618,14 @@ __global__ void k_scal_reset(DevScalars* s)
 // single-device update: the local maximum is the global one
 __global__ void k_scal_lwmax_local(DevScalars* s) { s->lwmax = s->lwmax_bits ? order_decode(s->lwmax_bits) : -__builtin_inf(); }
 __global__ void k_scal_total_local(DevScalars* s) { s->w_off = 0ULL; s->w_total = s->w_local; }
+// the device-side hand-over of the phased update: local maximum out, global maximum in, local totals out
+__global__ void k_scal_export_lwmax(const DevScalars* s, double* out) { out[0] = s->lwmax_bits ? order_decode(s->lwmax_bits) : -__builtin_inf(); }
+__global__ void k_scal_import_lwmax(DevScalars* s, const double* in) { s->lwmax = in[0]; }
+__global__ void k_scal_export_totals(const DevScalars* s, double* out)
+{
+    out[0] = (double)s->w_local; out[1] = s->sumsq; out[2] = (double)s->flags; out[3] = s->lwmax;
+}
+__global__ void k_scal_set_offsets(DevScalars* s, unsigned long long off, unsigned long long total) { s->w_off = off; s->w_total = total; }
 
 __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restrict__ lw, const DevScalars* __restrict__ scal, int F,
                                                unsigned long long* __restrict__ blocksum, double* __restrict__ blocksq)
@@ -1025,7 +1035,8 @@ int epi_ctx_create(int device, epi_ctx** out)
     HIPCHECK(hipSetDevice(device));
     epi_ctx* c = new epi_ctx();
     c->device = device;
-    HIPCHECK(hipStreamCreate(&c->stream));
+    HIPCHECK(hipStreamCreate(&c->own_stream));
+    c->stream = c->own_stream;
     HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
     HIPCHECK(hipMemset(c->d_scal, 0, 256));
     HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
@@ -1051,12 +1062,22 @@ int epi_ctx_destroy(epi_ctx* c)
     if (c->d_sums) (void)hipFree(c->d_sums);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_lf) (void)hipFree(c->d_lf);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return EPI_OK;
 }
 
 void* epi_ctx_stream(epi_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int epi_ctx_set_stream(epi_ctx* c, void* hip_stream, int adopt)
+{
+    if (!c) return fail(EPI_EINVAL, "epi_ctx_set_stream: ctx is NULL");
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    c->external = adopt != 0;
+    c->stream = c->external ? static_cast<hipStream_t>(hip_stream) : c->own_stream;     // a null handle is the default stream
+    return EPI_OK;
+}
 
 int epi_params_set(epi_ctx* c, const epi_params* p)
 {
@@ -1792,6 +1813,37 @@ int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_loc
     return EPI_OK;
 }
 
+int epi_pf_predict_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* d_lwmax_local)
+{
+    int rc = belief_check(b, "epi_pf_predict_dev");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_dev: bad argument");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict_dev: previous update not finished");
+    HIPCHECK(hipSetDevice(c->device));
+    rc = launch_predict(c, b, a, o, seed, step);
+    if (rc) return rc;
+    k_scal_export_lwmax<<<1, 1, 0, c->stream>>>(c->d_scal, d_lwmax_local);
+    HIPCHECK(hipGetLastError());
+    b->phase = PH_PREDICTED;
+    return EPI_OK;
+}
+
+int epi_pf_weigh_dev(epi_ctx* c, epi_belief* b, const double* d_lwmax_global, double* d_totals)
+{
+    int rc = belief_check(b, "epi_pf_weigh_dev");
+    if (rc) return rc;
+    if (!d_lwmax_global || !d_totals) return fail(EPI_EINVAL, "epi_pf_weigh_dev: NULL device pointer");
+    if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh_dev: call epi_pf_predict_dev first");
+    HIPCHECK(hipSetDevice(c->device));
+    k_scal_import_lwmax<<<1, 1, 0, c->stream>>>(c->d_scal, d_lwmax_global);
+    rc = launch_weigh(c, b);
+    if (rc) return rc;
+    k_scal_export_totals<<<1, 1, 0, c->stream>>>(c->d_scal, d_totals);
+    HIPCHECK(hipGetLastError());
+    b->phase = PH_WEIGHED;
+    return EPI_OK;
+}
+
 static inline int64_t shard_start(int64_t n_total, int G, int g) { return (int64_t)(((__int128)n_total * g) / G); }
 
 int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, uint32_t step, int64_t* lo)
@@ -1823,10 +1875,10 @@ int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, 
 
 static int set_offsets(epi_ctx* c, int G, int shard, const uint64_t* w_shard)
 {
-    unsigned long long v[2] = {0ULL, 0ULL};     // w_off, w_total
-    for (int g = 0; g < G; g++) { if (g < shard) v[0] += w_shard[g]; v[1] += w_shard[g]; }
-    HIPCHECK(hipMemcpyAsync(&c->d_scal->w_off, v, sizeof v, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    unsigned long long off = 0ULL, total = 0ULL;
+    for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
+    k_scal_set_offsets<<<1, 1, 0, c->stream>>>(c->d_scal, off, total);
+    HIPCHECK(hipGetLastError());
     return EPI_OK;
 }
 
@@ -1867,7 +1919,7 @@ int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w
                                                                              b->n, c->d_scal, b->n_total, u, b->buf[b->cur ^ 1], b->stride, b->rows,
                                                                              static_cast<int32_t*>(dev_buf));
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
     return EPI_OK;
 }
 
@@ -1885,7 +1937,7 @@ int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_en
     k_import<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin - b->slot0, b->n + b->halo_used, static_cast<const int32_t*>(dev_buf),
                                                                              b->buf[b->cur ^ 1], b->stride, b->rows, b->anc);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
     b->halo_used += count;
     return EPI_OK;
 }
@@ -1896,9 +1948,11 @@ int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
     if (rc) return rc;
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_finish: no update in progress");
     HIPCHECK(hipSetDevice(c->device));
-    rc = fetch_flags(c, flags, true);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (flags) {
+        rc = fetch_flags(c, flags, true);
+        if (rc) return rc;
+    } else HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+    if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
     b->cur ^= 1; b->has_anc = true; b->phase = PH_IDLE;
     return EPI_OK;
 }

@@ -12,8 +12,10 @@ src/POMDPsInterface.jl:56, src/MPC.jl:393):
   1. local fused weight + step                          (no communication)
   2. all-reduce MAX of the local maximum log weight     (1 double)
   3. local fixed-point weights + prefix sums
-  4. all-gather of the local weight totals, sums of squares and step flags
-     (3 values/rank)
+  4. all-gather of the local weight totals, sums of squares, step flags and the
+     global maximum (4 values/rank); with the device library steps 1-4 are only
+     enqueued (library and collectives share torch's current stream) and the host
+     waits here, once per update
   5. every rank derives the same plan: shard g's particles are the ancestors of
      global slots [lo[g], lo[g+1])
   6. slots of that range owned by another rank: the resampled particles are
@@ -51,6 +53,11 @@ class LibShard:
         check(self.lib.epi_belief_set_shard(self.b.handle, n_total, slot0))
         self.rows = self.lib.epi_state_rows(pomdp.horizon, pomdp.test_delay)
         self.comm_device = torch.device("cuda", device)
+        # the library works on torch's current stream, where the RCCL collectives are ordered too: the phases of
+        # an update are then only enqueued, and the host waits once per update (for the weight totals)
+        self.stream = torch.cuda.current_stream(self.comm_device)
+        check(self.lib.epi_ctx_set_stream(self.ctx.handle, C.c_void_p(self.stream.cuda_stream), 1))
+        self.shares_stream = True
 
     def init_normal(self, mu, sigma, seed):
         check(self.lib.epi_belief_init_normal(self.b.handle, mu, sigma, seed))
@@ -65,6 +72,15 @@ class LibShard:
         v = C.c_double()
         check(self.lib.epi_pf_predict(self.ctx.handle, self.b.handle, a, int(o), seed, step, C.byref(v)))
         return v.value
+
+    def predict_dev(self, a, o, seed, step, lwmax_out):
+        """lwmax_out: 1-element float64 device tensor that receives the local maximum log weight."""
+        check(self.lib.epi_pf_predict_dev(self.ctx.handle, self.b.handle, a, int(o), seed, step, C.c_void_p(lwmax_out.data_ptr())))
+
+    def weigh_dev(self, lwmax_global, totals_out):
+        """lwmax_global: 1-element device tensor; totals_out: 4-element device tensor (w, sum w^2, flags, lwmax)."""
+        check(self.lib.epi_pf_weigh_dev(self.ctx.handle, self.b.handle, C.c_void_p(lwmax_global.data_ptr()),
+                                        C.c_void_p(totals_out.data_ptr())))
 
     def weigh(self, lwmax):
         w, sq, fl = C.c_uint64(), C.c_double(), C.c_uint32()
@@ -94,12 +110,13 @@ class LibShard:
         return self.torch.empty(self.rows * count, dtype=self.torch.int32, device=self.comm_device)
 
     def import_(self, s0, s1, buf):
-        self.torch.cuda.current_stream().synchronize()
+        if not self.shares_stream:
+            self.torch.cuda.current_stream().synchronize()
         check(self.lib.epi_pf_import(self.ctx.handle, self.b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
 
-    def finish(self) -> int:
+    def finish(self, want_flags: bool = True) -> int:
         fl = C.c_uint32()
-        check(self.lib.epi_pf_finish(self.ctx.handle, self.b.handle, C.byref(fl)))
+        check(self.lib.epi_pf_finish(self.ctx.handle, self.b.handle, C.byref(fl) if want_flags else None))
         return fl.value
 
     def sums(self) -> np.ndarray:
@@ -158,22 +175,32 @@ class ShardedFilter:
         torch, dist = self.torch, self.dist
         G, g, seed, step = self.world, self.rank, self.seed, self.step
         sh = self.shard
-        # 1-2: fused weight + step, global maximum log weight
-        t = torch.tensor([sh.predict(a, o, seed, step)], dtype=torch.float64, device=self.comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        lwmax = t.item()
-        # 3-4: local fixed-point weights, totals of every shard
-        w_local, sq_local, fl_local = sh.weigh(lwmax)
-        # totals are < 2^53 and flags < 2^32: exact as doubles
-        mine = torch.tensor([float(w_local), sq_local, float(fl_local)], dtype=torch.float64, device=self.comm_device)
-        allv = torch.empty(3 * G, dtype=torch.float64, device=self.comm_device)
+        device_handover = hasattr(sh, "predict_dev")
+        if device_handover:
+            # 1-4 without a host round trip: the library's kernels and the collectives are ordered on one stream
+            t = torch.empty(1, dtype=torch.float64, device=self.comm_device)
+            sh.predict_dev(a, o, seed, step, t)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mine = torch.empty(4, dtype=torch.float64, device=self.comm_device)
+            sh.weigh_dev(t, mine)
+        else:
+            # 1-2: fused weight + step, global maximum log weight
+            t = torch.tensor([sh.predict(a, o, seed, step)], dtype=torch.float64, device=self.comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            lwmax = t.item()
+            # 3-4: local fixed-point weights, totals of every shard
+            w_local, sq_local, fl_local = sh.weigh(lwmax)
+            # totals are < 2^53 and flags < 2^32: exact as doubles
+            mine = torch.tensor([float(w_local), sq_local, float(fl_local), lwmax], dtype=torch.float64, device=self.comm_device)
+        allv = torch.empty(4 * G, dtype=torch.float64, device=self.comm_device)
         dist.all_gather_into_tensor(allv, mine)
-        allv = allv.cpu().tolist()                                         # one device-to-host copy
-        w_shard = [int(allv[3 * h]) for h in range(G)]
-        sumsq = math.fsum(allv[3 * h + 1] for h in range(G))
+        allv = allv.cpu().tolist()                                         # the update's one wait for the device
+        w_shard = [int(allv[4 * h]) for h in range(G)]
+        sumsq = math.fsum(allv[4 * h + 1] for h in range(G))
+        lwmax = allv[3]
         flags = 0
         for h in range(G):
-            flags |= int(allv[3 * h + 2])
+            flags |= int(allv[4 * h + 2])
         # 5: the plan (identical on every rank)
         lo = sh.plan(self.n_total, w_shard, seed, step)
         st = self.starts
@@ -198,7 +225,10 @@ class ShardedFilter:
         s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
         if s1 > s0:
             sh.select_local(g, w_shard, seed, step, s0, s1)
-        sh.finish()
+        if device_handover:
+            sh.finish(want_flags=False)
+        else:
+            sh.finish()
         W = sum(w_shard)
         if W == 0:
             flags |= _lib.EPI_F_ZERO_W

@@ -200,6 +200,14 @@ int epi_pf_frac_bits(int64_t n_total);
 int epi_pf_predict(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step, double *lwmax_local);
 int epi_pf_weigh(epi_ctx *ctx, epi_belief *b, double lwmax_global, uint64_t *w_local, double *sumsq_local,
                  uint32_t *flags_local);
+/* The first two phases without a host round trip, for a host that runs the exchange on the same HIP
+ * stream (epi_ctx_set_stream): the local maximum is written to, the global maximum read from, device
+ * memory, and d_totals receives {local weight total, local sum of squares, local flags, global maximum}
+ * as four doubles (totals are < 2^53, exact). */
+int epi_pf_predict_dev(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step,
+                       double *d_lwmax_local /* device, 1 double */);
+int epi_pf_weigh_dev(epi_ctx *ctx, epi_belief *b, const double *d_lwmax_global /* device, 1 double */,
+                     double *d_totals /* device, 4 doubles */);
 int epi_pf_plan(int64_t n_total, int n_shards, const uint64_t *w_shard, uint64_t seed, uint32_t step,
                 int64_t *lo /* n_shards + 1 */);
 int epi_pf_select_local(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const uint64_t *w_shard,
@@ -207,7 +215,7 @@ int epi_pf_select_local(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, co
 int epi_pf_export(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const uint64_t *w_shard,
                   uint64_t seed, uint32_t step, int64_t slot_begin, int64_t slot_end, void *dev_buf);
 int epi_pf_import(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t slot_end, const void *dev_buf);
-int epi_pf_finish(epi_ctx *ctx, epi_belief *b, uint32_t *flags);
+int epi_pf_finish(epi_ctx *ctx, epi_belief *b, uint32_t *flags /* NULL: do not fetch */);
 
 /* ---- belief summaries ------------------------------------------------------- */
 
@@ -230,6 +238,12 @@ int epi_belief_sample(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr,
 /* The context's HIP stream (hipStream_t) so that callers can bracket work with
  * their own events. */
 void *epi_ctx_stream(epi_ctx *ctx);
+/* adopt != 0: use the caller's HIP stream (hipStream_t; a null handle is the default stream; e.g. torch's
+ * current stream, on which its RCCL collectives are ordered) for all further work of the context;
+ * adopt == 0 restores the context's own stream.  On an
+ * adopted stream epi_pf_export / epi_pf_import / epi_pf_select_local / epi_pf_finish(flags = NULL) only
+ * enqueue work: ordering with the caller's kernels and collectives is the stream's. */
+int epi_ctx_set_stream(epi_ctx *ctx, void *hip_stream, int adopt);
 /* Asynchronous variant of epi_pf_update: enqueues the whole update on the
  * context's stream and returns without synchronising; diagnostics stay on the
  * device until epi_pf_collect. */
