@@ -766,9 +766,10 @@ __device__ __forceinline__ int64_t find_ancestor(const unsigned long long* __res
 struct BigRange { long long a, b; long long idx; };
 constexpr int SMALL_RANGE = 8, BIG_RANGE = 8192;
 
-__device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw, double u, int64_t n_total)
+// (inv_stepw ~ 1 / stepw only seeds the guess; the two loops make the result exact whatever its rounding)
+__device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw, double inv_stepw, double u, int64_t n_total)
 {
-    const double guess = __builtin_ceil((double)c / stepw - u);
+    const double guess = __builtin_ceil((double)c * inv_stepw - u);
     int64_t m = guess < 0.0 ? 0 : (guess > (double)n_total ? n_total : (int64_t)guess);
     while (m > 0 && (unsigned long long)__builtin_floor(((double)(m - 1) + u) * stepw) >= c) m--;
     while (m < n_total && (unsigned long long)__builtin_floor(((double)m + u) * stepw) < c) m++;
@@ -787,12 +788,13 @@ __global__ __launch_bounds__(TPB) void k_scatter(int64_t n_local, const unsigned
         return;
     }
     const double stepw = (double)W / (double)n_total;
+    const double inv_stepw = (double)n_total / (double)W;
     const unsigned long long off = scal->w_off;
     const int lane = threadIdx.x & 63;
     int64_t b = slot_hi;
-    if (act && i < n_local - 1) b = first_slot(off + cum[i], stepw, u, n_total);
+    if (act && i < n_local - 1) b = first_slot(off + cum[i], stepw, inv_stepw, u, n_total);
     int64_t a = (int64_t)shfl_up_u64((unsigned long long)b, 1);
-    if (lane == 0) a = (act && i > 0) ? first_slot(off + cum[i - 1], stepw, u, n_total) : slot_lo;
+    if (lane == 0) a = (act && i > 0) ? first_slot(off + cum[i - 1], stepw, inv_stepw, u, n_total) : slot_lo;
     if (i == 0) a = slot_lo;
     a = a < slot_lo ? slot_lo : a;
     b = b > slot_hi ? slot_hi : b;

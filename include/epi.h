@@ -101,7 +101,8 @@ int64_t epi_belief_size(const epi_belief *b);
 int epi_belief_upload(epi_belief *b, const int64_t *S, const int64_t *I, const int64_t *R, const int64_t *T);
 int epi_belief_download(epi_belief *b, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
 /* Copy src into dst (same shape): beliefs have value semantics in the reference
- * (beliefHist[day] = b, src/POMDPsInterface.jl:53). */
+ * (beliefHist[day] = b, src/POMDPsInterface.jl:53).  The copy resolves src's pending
+ * resampling indirection on the way; src itself is not modified. */
 int epi_belief_copy(epi_belief *dst, epi_belief *src);
 
 /* Initial particles generated on the device.
