@@ -111,6 +111,15 @@ struct epi_belief {
     uint64_t seed = 0; uint32_t step = 0;
 };
 
+struct epi_ensemble {
+    epi_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int T = 0;
+    int32_t* hist = nullptr;            // [T][4][n]: S, sum I, R before each day's step, sum pos of the day
+    double* act = nullptr;              // [n]: the trajectory's (first-day) action, for the controlled ODE models
+    double* partial = nullptr;          // per-workgroup partial sums of a loss evaluation, then the total
+};
+
 static const int TPB = 256;            // threads per workgroup
 static const int LF_TABLE_N = 1 << 20; // tabulated log factorials (8 MB per context); larger arguments are computed
 static const int SCAN_ITEMS = 8;       // fixed-point weights per thread in the scan kernels
@@ -1014,6 +1023,94 @@ __global__ __launch_bounds__(TPB) void k_init_simplex(int64_t n, int32_t* __rest
     for (int r = 2 + H; r < rows; r++) out[(int64_t)r * stride + m] = 0;
 }
 
+// ---------------------------------------------------------------------------
+// ODE-model loss of an ensemble kept on the device
+//   hist: int32 [T][4][n] (S, sum I, R, sum pos before / of each day), one thread per trajectory.
+//   The compartment model (src/ODEFit.jl:1-37) starts from the trajectory's day-1 proportions and is
+//   integrated with classical Runge-Kutta, `sub` steps per day; the squared error against the
+//   trajectory's proportions is taken at every day (src/ODEFit.jl:281-340).
+// ---------------------------------------------------------------------------
+enum { ODE_SIR = 0, ODE_SIR_CTRL = 1, ODE_SEIR = 2, ODE_SEIR_CTRL = 3 };
+
+struct OdeRates { double alpha, beta, gamma; };       // effective rates of one trajectory
+
+// u = (S, E, I, R); SIR models keep E = 0 and gamma unused
+__host__ __device__ __forceinline__ void ode_rhs(int seir, const OdeRates& k, const double u[4], double du[4])
+{
+    const double inf = k.beta * u[2] * u[0];
+    du[0] = -inf;
+    if (seir) {
+        du[1] = inf - k.gamma * u[1];
+        du[2] = k.gamma * u[1] - k.alpha * u[2];
+    } else {
+        du[1] = 0.0;
+        du[2] = inf - k.alpha * u[2];
+    }
+    du[3] = k.alpha * u[2];
+}
+
+__host__ __device__ __forceinline__ void ode_rk4_step(int seir, const OdeRates& k, double u[4], double h)
+{
+    double k1[4], k2[4], k3[4], k4[4], t[4];
+    ode_rhs(seir, k, u, k1);
+    for (int c = 0; c < 4; c++) t[c] = u[c] + (0.5 * h) * k1[c];
+    ode_rhs(seir, k, t, k2);
+    for (int c = 0; c < 4; c++) t[c] = u[c] + (0.5 * h) * k2[c];
+    ode_rhs(seir, k, t, k3);
+    for (int c = 0; c < 4; c++) t[c] = u[c] + h * k3[c];
+    ode_rhs(seir, k, t, k4);
+    for (int c = 0; c < 4; c++) u[c] = u[c] + (h / 6.0) * (((k1[c] + 2.0 * k2[c]) + 2.0 * k3[c]) + k4[c]);
+}
+
+__global__ __launch_bounds__(TPB) void k_ode_loss(int64_t n, int T, const int32_t* __restrict__ hist, const double* __restrict__ act,
+                                                   int kind, double p0, double p1, double p2, double p3, double p4, int sub, double Npop,
+                                                   double* __restrict__ per_traj, double* __restrict__ partial)
+{
+    __shared__ double s_p[TPB / 64];
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    double loss = 0.0;
+    if (m < n) {
+        const int seir = kind >= ODE_SEIR;
+        const double tp = (kind == ODE_SIR_CTRL || kind == ODE_SEIR_CTRL) ? act[m] : 0.0;
+        OdeRates k;
+        k.alpha = p0; k.beta = p1; k.gamma = 0.0;
+        if (kind == ODE_SIR_CTRL) k.alpha = p0 + p2 * tp;                         // alpha + delta T
+        if (kind == ODE_SEIR) k.gamma = p2;
+        if (kind == ODE_SEIR_CTRL) { k.gamma = p2 + p4 * tp; k.alpha = p0 + p3 * tp; }   // gamma + eps T, alpha + delta T
+        double u[4];
+        u[0] = (double)hist[m] / Npop; u[1] = 0.0; u[2] = (double)hist[n + m] / Npop; u[3] = (double)hist[2 * n + m] / Npop;
+        const double h = 1.0 / (double)sub;
+        for (int t = 0; t < T; t++) {
+            if (t > 0) for (int j = 0; j < sub; j++) ode_rk4_step(seir, k, u, h);
+            const int32_t* row = hist + (int64_t)t * 4 * n;
+            const double rs = (double)row[m] / Npop, ri = (double)row[n + m] / Npop, rr = (double)row[2 * n + m] / Npop;
+            const double e0 = u[0] - rs, e1 = (u[1] + u[2]) - ri, e2 = u[3] - rr;
+            loss += (e0 * e0 + e1 * e1) + e2 * e2;
+        }
+        if (per_traj) per_traj[m] = loss;
+    }
+    for (int d = 32; d >= 1; d >>= 1) loss += shfl_down_f64(loss, d);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((s_p[0] + s_p[1]) + s_p[2]) + s_p[3];
+}
+
+// sum of the per-workgroup partial sums in a fixed order (one workgroup)
+__global__ __launch_bounds__(1024) void k_sum_partials(int64_t count, const double* __restrict__ partial, double* __restrict__ out)
+{
+    __shared__ double s_p[16];
+    double t = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) t += partial[i];
+    for (int d = 32; d >= 1; d >>= 1) t += shfl_down_f64(t, d);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int w = 0; w < 16; w++) r += s_p[w];
+        out[0] = r;
+    }
+}
+
 struct DevBuf {          // device scratch freed on scope exit
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -1621,6 +1718,118 @@ int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts
     rc = fetch_flags(c, flags, true);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
+}
+
+// ---- ensembles kept on the device (ODE fitting) ------------------------------------
+
+int epi_ensemble_destroy(epi_ensemble* e)
+{
+    if (!e) return EPI_OK;
+    (void)hipSetDevice(e->ctx->device);
+    (void)hipStreamSynchronize(e->ctx->stream);
+    if (e->hist) (void)hipFree(e->hist);
+    if (e->act) (void)hipFree(e->act);
+    if (e->partial) (void)hipFree(e->partial);
+    delete e;
+    return EPI_OK;
+}
+
+int epi_ensemble_simulate(epi_ctx* c, epi_belief* b, int T, const double* actions, int act_per_particle, int act_per_day, double a_prev0,
+                          uint64_t seed, uint32_t step0, epi_ensemble** out, uint32_t* flags)
+{
+    int rc = belief_check(b, "epi_ensemble_simulate");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !actions || !out || T < 1) return fail(EPI_EINVAL, "epi_ensemble_simulate: bad argument");
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_ensemble_simulate: a phased update is in progress");
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = b->n;
+    const int64_t arow = act_per_day ? T : 1;
+    const size_t acount = (size_t)(act_per_particle ? n : 1) * (size_t)arow;
+    epi_ensemble* e = new epi_ensemble();
+    e->ctx = c; e->n = n; e->T = T;
+    DevBuf dact;
+    hipError_t he = dact.alloc(sizeof(double) * acount);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->hist, sizeof(int32_t) * 4 * (size_t)n * (size_t)T);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->act, sizeof(double) * (size_t)n);
+    if (he == hipSuccess) he = hipMalloc((void**)&e->partial, sizeof(double) * ((size_t)ceil_div(n, TPB) + 1));
+    if (he != hipSuccess) { epi_ensemble_destroy(e); return fail(EPI_ENOMEM, "epi_ensemble_simulate: hipMalloc failed: %s", hipGetErrorString(he)); }
+    HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * acount, hipMemcpyHostToDevice, c->stream));
+    {   // the action the controlled ODE models see: the trajectory's first-day action
+        std::vector<double> a0((size_t)n);
+        for (int64_t m = 0; m < n; m++) a0[(size_t)m] = actions[act_per_particle ? (size_t)m * (size_t)arow : 0];
+        HIPCHECK(hipMemcpyAsync(e->act, a0.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+    }
+    for (int t = 0; t < T; t++) {
+        StepArgs A;
+        memset(&A, 0, sizeof A);
+        A.screen = g_screen;
+        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+        const int64_t tcol = act_per_day ? t : 0;
+        A.a_row_stride = 1;
+        if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
+        else A.a = actions[tcol];
+        A.a_prev = a_prev0;                                   // rewards are not computed here
+        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+        A.hist = e->hist + (size_t)t * 4 * (size_t)n;
+        HIPCHECK(launch_step<false>(c, A));
+        b->cur ^= 1; b->has_anc = false;
+    }
+    rc = fetch_flags(c, flags, true);
+    if (rc) { epi_ensemble_destroy(e); return rc; }
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *out = e;
+    return EPI_OK;
+}
+
+int epi_ensemble_shape(const epi_ensemble* e, int64_t* n, int* T)
+{
+    if (!e) return fail(EPI_EINVAL, "epi_ensemble_shape: ensemble is NULL");
+    if (n) *n = e->n;
+    if (T) *T = e->T;
+    return EPI_OK;
+}
+
+int epi_ensemble_download(epi_ensemble* e, int64_t* hist)
+{
+    if (!e || !hist) return fail(EPI_EINVAL, "epi_ensemble_download: NULL argument");
+    epi_ctx* c = e->ctx;
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = e->n;
+    const int T = e->T;
+    std::vector<int32_t> h((size_t)4 * (size_t)n * (size_t)T);
+    HIPCHECK(hipMemcpyAsync(h.data(), e->hist, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    for (int64_t p = 0; p < n; p++)
+        for (int t = 0; t < T; t++)
+            for (int k = 0; k < 3; k++) hist[(p * T + t) * 3 + k] = h[((size_t)t * 4 + (size_t)k) * (size_t)n + (size_t)p];
+    return EPI_OK;
+}
+
+int epi_ensemble_loss(epi_ctx* c, epi_ensemble* e, int kind, const double* p, int n_p, int substeps, double* loss, double* per_traj)
+{
+    if (!c || !e || e->ctx != c || !p || !loss) return fail(EPI_EINVAL, "epi_ensemble_loss: bad argument");
+    static const int want[4] = {2, 3, 3, 5};              // parameters of SIR, SIR_CTRL, SEIR, SEIR_CTRL (src/ODEFit.jl:40-55)
+    if (kind < 0 || kind > 3) return fail(EPI_EINVAL, "epi_ensemble_loss: kind = %d", kind);
+    if (n_p != want[kind]) return fail(EPI_EINVAL, "epi_ensemble_loss: model %d takes %d parameters, got %d", kind, want[kind], n_p);
+    if (substeps < 1 || substeps > 4096) return fail(EPI_EINVAL, "epi_ensemble_loss: substeps = %d", substeps);
+    HIPCHECK(hipSetDevice(c->device));
+    double q[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < n_p; i++) q[i] = p[i];
+    DevBuf dper;
+    if (per_traj && dper.alloc(sizeof(double) * (size_t)e->n) != hipSuccess) return fail(EPI_ENOMEM, "epi_ensemble_loss: hipMalloc failed");
+    const int64_t nb = ceil_div(e->n, TPB);
+    k_ode_loss<<<dim3((unsigned)nb), dim3(TPB), 0, c->stream>>>(e->n, e->T, e->hist, e->act, kind, q[0], q[1], q[2], q[3], q[4], substeps,
+                                                              (double)c->P.N, per_traj ? dper.as<double>() : nullptr, e->partial);
+    k_sum_partials<<<1, 1024, 0, c->stream>>>(nb, e->partial, e->partial + nb);
+    HIPCHECK(hipGetLastError());
+    double total = 0.0;
+    HIPCHECK(hipMemcpyAsync(&total, e->partial + nb, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (per_traj) HIPCHECK(hipMemcpyAsync(per_traj, dper.p, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *loss = total / (double)e->n;                           // scaled by the number of simulations (src/ODEFit.jl:289)
     return EPI_OK;
 }
 

@@ -218,6 +218,37 @@ int epi_pf_export(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const ui
 int epi_pf_import(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t slot_end, const void *dev_buf);
 int epi_pf_finish(epi_ctx *ctx, epi_belief *b, uint32_t *flags /* NULL: do not fetch */);
 
+/* ---- ensembles kept on the device (ODE fitting, src/ODEFit.jl) ------------------ */
+
+typedef struct epi_ensemble epi_ensemble;   /* the histories of n trajectories over T days, resident in HBM */
+
+/* SimulateEnsemble (src/simulate.jl:210-227) with the histories left on the device: T days from the
+ * particles of b (which end at day T); actions as for epi_rollout_batch.  The ensemble records S, sum(I), R
+ * before each day's step (Array(::Vector{SimHist}), src/simulate.jl:291-297) and, per trajectory, its
+ * first-day action (the T component of the controlled models' initial condition, src/ODEFit.jl:236-239). */
+int epi_ensemble_simulate(epi_ctx *ctx, epi_belief *b, int T,
+                          const double *actions, int act_per_particle, int act_per_day, double a_prev0,
+                          uint64_t seed, uint32_t step0, epi_ensemble **out, uint32_t *flags);
+int epi_ensemble_destroy(epi_ensemble *e);
+int epi_ensemble_shape(const epi_ensemble *e, int64_t *n, int *T);
+/* hist: int64[n][T][3] = S, sum(I), R */
+int epi_ensemble_download(epi_ensemble *e, int64_t *hist);
+
+/* SIR_param_loss / SIR_CTRL_param_loss / SEIR_param_loss / SEIR_CTRL_param_loss (src/ODEFit.jl:281-340):
+ * for every trajectory the compartment model `kind` (src/ODEFit.jl:1-37) is integrated from the
+ * trajectory's day-1 proportions over days 1..T and the squared error against the trajectory's
+ * proportions is summed over days and compartments (SEIR: E + I against the infected count);
+ * loss = that sum over trajectories / n.  p: alpha, beta | alpha, beta, delta | alpha, beta, gamma |
+ * alpha, beta, gamma, delta, eps.  The reference calls an adaptive solver at its default tolerance
+ * (1e-3 relative); here: classical Runge-Kutta with `substeps` steps per day.  per_traj (optional):
+ * double[n], each trajectory's own sum. */
+#define EPI_ODE_SIR       0
+#define EPI_ODE_SIR_CTRL  1
+#define EPI_ODE_SEIR      2
+#define EPI_ODE_SEIR_CTRL 3
+int epi_ensemble_loss(epi_ctx *ctx, epi_ensemble *e, int kind, const double *p, int n_p, int substeps,
+                      double *loss, double *per_traj);
+
 /* ---- belief summaries ------------------------------------------------------- */
 
 /* Integer column sums over the particles of b: sums[0] = sum S, sums[1] = sum R,

@@ -479,3 +479,50 @@ def test_sharded_filter_over_rccl_single_rank(tmp_path):
         assert mS == eS and mR == eR and (mI == eI).all()
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------
+# ensembles kept on the device and the ODE-model losses
+# ---------------------------------------------------------------------------
+def test_ensemble_history_and_ode_losses():
+    """The device ensemble equals the oracle's rollouts day for day; every trajectory's ODE loss equals the numpy
+    restatement bit for bit (same operation order), the mean to 1e-12 relative (the reduction order differs)."""
+    from oracle import odeloss_numpy as ol
+    pomdp = em.make_pomdp(LOD=5)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n, T = 700, 18
+    st = orc.init_simplex(n, 21)
+    rng = np.random.default_rng(4)
+    acts = rng.random(n)
+    b = _belief(pomdp, st)
+    ens = em.Ensemble(b, T, acts, seed=31, step0=1)
+    _, ehist, _, efl = orc.rollout(st, T, acts, seed=31, step0=1)
+    arr = ens.Array()
+    assert arr.shape == (3, T, n) and ens.flags == efl
+    assert (arr == np.transpose(ehist[:, :, :3], (2, 1, 0))).all()
+    for kind, p in (("SIR", [0.12, 0.31]), ("SIR_CTRL", [0.1, 0.3, 0.2]), ("SEIR", [0.12, 0.5, 0.8]),
+                    ("SEIR_CTRL", [0.1, 0.4, 0.7, 0.3, 0.5])):
+        for sub in (1, 8):
+            got, pt = ens.loss(kind, p, substeps=sub, per_trajectory=True)
+            ref = ol.per_trajectory_loss(ehist[:, :, :3], pomdp.N, em.odefit.KINDS[kind], p, acts, sub)
+            assert (pt.view(np.uint64) == ref.view(np.uint64)).all(), kind
+            assert abs(got - ref.sum() / n) <= 1e-12 * abs(got)
+    with pytest.raises(_lib.EpiError):
+        ens.loss("SIR", [0.1, 0.2, 0.3])
+    ens.close()
+
+
+def test_ode_fit_on_the_device_ensemble():
+    """FitRandEnsemble / FitRandControlledEnsemble (src/ODEFit.jl:166-273): Nelder-Mead over the device loss
+    ends below the loss of the first guess, with positive rates, reproducibly."""
+    pomdp = em.make_pomdp(LOD=5)
+    res, p = em.FitRandEnsemble("SIR", 30, 2000, pomdp, em.Action(0.1), seed=5)
+    assert len(p) == 2 and res.fun < 0.5 and p[0] > 0 and p[1] > 0
+    b = em.random_states(pomdp, 2000, seed=5)
+    ens = em.Ensemble(b, 30, 0.1, seed=5)
+    assert res.fun <= ens.loss("SIR", [0.1, 0.1]) and abs(ens.loss("SIR", p) - res.fun) <= 1e-15
+    ens.close()
+    res2, p2 = em.FitRandEnsemble("SIR", 30, 2000, pomdp, em.Action(0.1), seed=5)
+    assert p2 == p
+    res3, p3 = em.FitRandControlledEnsemble("SEIR", 20, 1000, pomdp, seed=6)
+    assert len(p3) == 5 and np.isfinite(res3.fun)
