@@ -1024,6 +1024,41 @@ __global__ __launch_bounds__(TPB) void k_init_simplex(int64_t n, int32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
+// order statistics of the infected total sum(I) over the particles of a belief (radix select, 11 + 11 + 9 bits)
+// ---------------------------------------------------------------------------
+constexpr int QSEL_MAX = 4;            // quantiles per call
+constexpr int QSEL_BINS = 2048;
+
+__global__ __launch_bounds__(TPB) void k_suminf(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
+                                                 int H, int32_t* __restrict__ out)
+{
+    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (m >= n) return;
+    const int64_t a = anc ? (int64_t)anc[m] : m;
+    int32_t t = 0;
+    for (int i = 0; i < H; i++) t += src[(int64_t)(2 + i) * stride + a];
+    out[m] = t;
+}
+
+// histogram of the digit (v >> shift) & (bins - 1) of the values whose higher digits equal prefix[j] (pass 0: all)
+struct QselPass { unsigned int prefix[QSEL_MAX]; int nq, shift, bins, hi_shift; };
+__global__ __launch_bounds__(TPB) void k_qsel_hist(int64_t n, const int32_t* __restrict__ v, QselPass P, unsigned long long* __restrict__ hist)
+{
+    __shared__ unsigned int s_h[QSEL_MAX * QSEL_BINS];
+    for (int i = threadIdx.x; i < P.nq * QSEL_BINS; i += TPB) s_h[i] = 0u;
+    __syncthreads();
+    for (int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x; m < n; m += (int64_t)gridDim.x * TPB) {
+        const unsigned int x = (unsigned int)v[m];
+        const unsigned int d = (x >> P.shift) & (unsigned int)(P.bins - 1);
+        for (int j = 0; j < P.nq; j++)
+            if (P.hi_shift >= 32 || (x >> P.hi_shift) == P.prefix[j]) atomicAdd(&s_h[j * QSEL_BINS + d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P.nq * QSEL_BINS; i += TPB)
+        if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+}
+
+// ---------------------------------------------------------------------------
 // ODE-model loss of an ensemble kept on the device
 //   hist: int32 [T][4][n] (S, sum I, R, sum pos before / of each day), one thread per trajectory.
 //   The compartment model (src/ODEFit.jl:1-37) starts from the trajectory's day-1 proportions and is
@@ -2216,6 +2251,56 @@ int epi_belief_mean(epi_ctx* c, epi_belief* b, int64_t* S, int64_t* I, int64_t* 
     int rc = epi_belief_sums(c, b, sums);
     if (rc) return rc;
     return epi_mean_from_sums(&c->P, b->n, sums, S, I, R, T);
+}
+
+int epi_belief_suminf_quantiles(epi_ctx* c, epi_belief* b, const double* q, int nq, int64_t* out)
+{
+    int rc = belief_check(b, "epi_belief_suminf_quantiles");
+    if (rc) return rc;
+    if (!c || b->ctx != c || !q || !out || nq < 1 || nq > QSEL_MAX) return fail(EPI_EINVAL, "epi_belief_suminf_quantiles: 1 to %d quantiles", QSEL_MAX);
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_suminf_quantiles: a phased update is in progress");
+    for (int j = 0; j < nq; j++) if (!(q[j] >= 0.0 && q[j] <= 1.0)) return fail(EPI_EINVAL, "epi_belief_suminf_quantiles: q[%d] = %g", j, q[j]);
+    HIPCHECK(hipSetDevice(c->device));
+    const int64_t n = b->n;
+    DevBuf dv, dh;
+    if (dv.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess || dh.alloc(sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS) != hipSuccess)
+        return fail(EPI_ENOMEM, "epi_belief_suminf_quantiles: hipMalloc failed");
+    k_suminf<<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->P.H, dv.as<int32_t>());
+    // 1-based rank of each quantile: the smallest value with at least ceil(q n) values <= it (rank 1 for q = 0)
+    int64_t rank[QSEL_MAX];
+    for (int j = 0; j < nq; j++) {
+        int64_t r = (int64_t)ceil(q[j] * (double)n);
+        rank[j] = r < 1 ? 1 : (r > n ? n : r);
+    }
+    QselPass P;
+    memset(&P, 0, sizeof P);
+    P.nq = nq;
+    const int shifts[3] = {20, 9, 0}, bins[3] = {2048, 2048, 512};
+    std::vector<unsigned long long> h((size_t)QSEL_MAX * QSEL_BINS);
+    int64_t gx = ceil_div(n, (int64_t)TPB * 16);
+    gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
+    for (int pass = 0; pass < 3; pass++) {
+        P.shift = shifts[pass]; P.bins = bins[pass]; P.hi_shift = pass == 0 ? 32 : shifts[pass - 1];
+        HIPCHECK(hipMemsetAsync(dh.p, 0, sizeof(unsigned long long) * h.size(), c->stream));
+        k_qsel_hist<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(n, dv.as<int32_t>(), P, dh.as<unsigned long long>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(h.data(), dh.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int j = 0; j < nq; j++) {
+            unsigned long long acc = 0;
+            int d = 0;
+            for (; d < bins[pass]; d++) {
+                const unsigned long long cnt = h[(size_t)j * QSEL_BINS + (size_t)d];
+                if (acc + cnt >= (unsigned long long)rank[j]) break;
+                acc += cnt;
+            }
+            if (d == bins[pass]) return fail(EPI_ESTATE, "epi_belief_suminf_quantiles: rank not found (internal)");
+            rank[j] -= (int64_t)acc;
+            P.prefix[j] = (pass == 0 ? 0u : (P.prefix[j] << (shifts[pass - 1] - shifts[pass]))) | (unsigned int)d;
+        }
+    }
+    for (int j = 0; j < nq; j++) out[j] = (int64_t)P.prefix[j];
+    return EPI_OK;
 }
 
 int epi_belief_sample(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr, int64_t* S, int64_t* I, int64_t* R, int64_t* T)

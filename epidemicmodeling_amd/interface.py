@@ -293,6 +293,28 @@ def mean(b: ParticleCollection, pomdp: Optional[CovidPOMDP] = None) -> State:
     return State(S.value, I, R.value, T.T.copy(), b.prev_action)
 
 
+def suminf_quantiles(b: ParticleCollection, q) -> np.ndarray:
+    """Order statistics of sum(I) over the particles of b, computed on the device: for each q the smallest
+    value with at least ceil(q n) particles at or below it."""
+    qs = np.ascontiguousarray(np.atleast_1d(np.asarray(q, dtype=np.float64)))
+    out = np.empty(qs.size, dtype=np.int64)
+    for k in range(0, qs.size, 4):
+        part = np.ascontiguousarray(qs[k:k + 4])
+        res = np.empty(part.size, dtype=np.int64)
+        check(b.ctx.lib.epi_belief_suminf_quantiles(b.ctx.handle, b.handle, as_f64p(part), part.size, as_i64p(res)))
+        out[k:k + 4] = res
+    return out
+
+
+@dataclass
+class BeliefSummary:
+    """What a plot of a belief history needs of one day's belief (src/plots.jl:47): the mean state and a few
+    order statistics of the infected total."""
+    mean: State
+    q: np.ndarray
+    suminf_q: np.ndarray
+
+
 # ---------------------------------------------------------------------------
 # rollouts
 # ---------------------------------------------------------------------------
@@ -416,7 +438,9 @@ def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: Covid
                        planner: Callable[[ParticleCollection], Action], seed: int = _DEFAULT_SEED,
                        keep_beliefs: bool = False) -> SimHist:
     """Simulate(T, state, b, pomdp, planner) (src/POMDPsInterface.jl:29-62):
-    plan every test_period days, step the true state, update the belief."""
+    plan every test_period days, step the true state, update the belief.
+    keep_beliefs: False, True (a copy of every day's belief, as the reference keeps) or "summary" (per day the
+    mean state and the 5 / 50 / 95 % order statistics of sum(I), reduced on the device)."""
     single = unity_test_period(pomdp)
     upd = BootstrapFilter(single, n_particles(b), seed=seed)
     sus, inf, rec = (np.zeros(T, dtype=np.int64) for _ in range(3))
@@ -428,7 +452,10 @@ def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: Covid
         action = planner(b) if day % pomdp.test_period == 0 else actions[day - 1]
         sus[day], inf[day], rec[day] = state.S, int(state.I.sum()), state.R
         actions.append(action)
-        if keep_beliefs:
+        if keep_beliefs == "summary":
+            qs = np.array([0.05, 0.5, 0.95])
+            beliefs.append(BeliefSummary(mean(b), qs, suminf_quantiles(b, qs)))
+        elif keep_beliefs:
             beliefs.append(b.copy())
         state, o, r = gen(single, state, action, seed=seed ^ 0x7275E, step=day)
         b = update(upd, b, action, o)

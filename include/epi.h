@@ -261,6 +261,11 @@ int epi_belief_sums(epi_ctx *ctx, epi_belief *b, int64_t *sums /* 2 + H + (D+1) 
 int epi_belief_mean(epi_ctx *ctx, epi_belief *b, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
 int epi_mean_from_sums(const epi_params *p, int64_t n_total, const int64_t *sums,
                        int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+/* Order statistics of the infected total sum(I) over the particles of b (per-day belief summaries for
+ * plotting a belief history, src/plots.jl:40-54, without keeping the ParticleCollections of
+ * src/POMDPsInterface.jl:53): out[j] = the smallest value v such that at least ceil(q[j] n) particles have
+ * sum(I) <= v (the minimum for q = 0).  1 to 4 quantiles per call. */
+int epi_belief_suminf_quantiles(epi_ctx *ctx, epi_belief *b, const double *q, int nq, int64_t *out);
 /* rand(rng, b): one particle, uniformly (src/updater.jl:2 pattern; POMCPOW
  * samples states from the belief). */
 int epi_belief_sample(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr,

@@ -526,3 +526,26 @@ def test_ode_fit_on_the_device_ensemble():
     assert p2 == p
     res3, p3 = em.FitRandControlledEnsemble("SEIR", 20, 1000, pomdp, seed=6)
     assert len(p3) == 5 and np.isfinite(res3.fun)
+
+
+def test_suminf_quantiles_and_belief_summaries():
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    for n in (1, 7, 50_001):
+        st = orc.init_normal(n, 10_000.0, 5_000.0, 3)
+        b = _belief(pomdp, st)
+        upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+        _, mu, _ = orc.log_weights(st, 0.3, 0)
+        em.update(upd, b, em.Action(0.3), int(np.median(mu)))          # leaves a pending ancestor indirection
+        S, I, R, T = b.download()
+        tot = np.sort(I.sum(axis=1))
+        qs = np.array([0.0, 0.05, 0.5, 0.95, 1.0, 0.3333])
+        got = em.suminf_quantiles(b, qs)
+        ranks = np.clip(np.ceil(qs * n).astype(np.int64), 1, n)
+        assert (got == tot[ranks - 1]).all(), (n, got, tot[ranks - 1])
+    true = em.State_from((10_000.0, 5_000.0), pomdp, np.random.default_rng(0))
+    b = em.initialbelief(pomdp, 20_000, seed=SEED)
+    h = em.SimulateClosedLoop(5, true, b, pomdp, lambda bel: em.Action(0.2), seed=9, keep_beliefs="summary")
+    assert len(h.beliefs) == 5
+    for s in h.beliefs:
+        assert s.suminf_q[0] <= s.suminf_q[1] <= s.suminf_q[2] and s.suminf_q[0] <= int(s.mean.I.sum()) <= s.suminf_q[2]
