@@ -549,3 +549,50 @@ def test_suminf_quantiles_and_belief_summaries():
     assert len(h.beliefs) == 5
     for s in h.beliefs:
         assert s.suminf_q[0] <= s.suminf_q[1] <= s.suminf_q[2] and s.suminf_q[0] <= int(s.mean.I.sum()) <= s.suminf_q[2]
+
+
+# ---------------------------------------------------------------------------
+# error behaviour of the C ABI
+# ---------------------------------------------------------------------------
+def test_error_codes_and_messages():
+    lib = _lib.load()
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    ctx = em.interface.context_for(pomdp)
+    n = 100
+    b = em.initialbelief(pomdp, n, seed=1)
+
+    def code(call):
+        rc = call()
+        assert rc != 0 and lib.epi_last_error().decode()
+        return rc
+
+    bad = pomdp.to_c()
+    bad.N = 2 ** 31                                                                 # counts are int32 on the device
+    assert code(lambda: lib.epi_params_set(ctx.handle, C.byref(bad))) == -4        # EPI_ERANGE
+    bad = pomdp.to_c()
+    bad.p[3] = 1.5
+    assert code(lambda: lib.epi_params_set(ctx.handle, C.byref(bad))) == -1        # EPI_EINVAL
+    h = C.c_void_p()
+    assert code(lambda: lib.epi_belief_create(ctx.handle, 0, 0, C.byref(h))) == -1
+    assert code(lambda: lib.epi_ctx_create(10_000, C.byref(h))) == -1
+    # phases out of order
+    w, sq = C.c_uint64(), C.c_double()
+    assert code(lambda: lib.epi_pf_weigh(ctx.handle, b.handle, 0.0, C.byref(w), C.byref(sq), None)) == -5     # EPI_ESTATE
+    assert code(lambda: lib.epi_pf_finish(ctx.handle, b.handle, None)) == -5
+    v = C.c_double()
+    check(lib.epi_pf_predict(ctx.handle, b.handle, 0.2, 100, 1, 0, C.byref(v)))
+    assert code(lambda: lib.epi_pf_update(ctx.handle, b.handle, 0.2, 100, 1, 0, None, None, None)) == -5
+    check(lib.epi_pf_weigh(ctx.handle, b.handle, v.value, C.byref(w), C.byref(sq), None))
+    assert code(lambda: lib.epi_pf_select_local(ctx.handle, b.handle, 1, 0, C.byref(w), 1, 0, 0, n + 1)) == -1   # slots not owned
+    check(lib.epi_pf_select_local(ctx.handle, b.handle, 1, 0, C.byref(w), 1, 0, 0, n))
+    check(lib.epi_pf_finish(ctx.handle, b.handle, None))
+    # states that violate the stored layout (Tests row D+1 / column 1 must be zero) are rejected on upload
+    S, I, R, T = b.download()
+    T2 = T.copy()
+    T2[0, 0, 0] = 1
+    with pytest.raises(_lib.EpiError):
+        b.upload(S, I, R, T2)
+    # a sharded belief refuses the one-call update
+    check(lib.epi_belief_set_shard(b.handle, 2 * n, n))
+    assert code(lambda: lib.epi_pf_update(ctx.handle, b.handle, 0.2, 100, 1, 1, None, None, None)) == -5
+    b.close()
