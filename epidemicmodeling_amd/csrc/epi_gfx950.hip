@@ -591,15 +591,18 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
 
 static size_t coop_lds_bytes(int H) { return (size_t)H * TPB * 8 + 2 * QCAP * sizeof(unsigned short) + 2 * sizeof(unsigned int) + (TPB / 64) * sizeof(unsigned long long); }
 
-static int g_coop = 1;       // see epi_debug_step_impl
+static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by state width, 2 cooperative
 
 // launch the Philox-driven step with the selected implementation
 template <bool WEIGH>
 static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
 {
     const dim3 grid((unsigned)ceil_div(A.n, TPB)), blk(TPB);
-    if (g_coop) {
-        const size_t lds = coop_lds_bytes(c->P.H);
+    // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 15 four workgroups share a CU and it is
+    // the faster one (2.2 vs 1.6e9 particle-steps/s at H = 14); wider states leave it one or two workgroups per CU
+    // and the per-thread kernel wins (H = 28: 0.72 vs 0.88e9, H = 56: 0.25 vs 0.54e9).
+    const size_t lds = coop_lds_bytes(c->P.H);
+    if (g_coop == 2 || (g_coop == 1 && lds <= 40 * 1024)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
@@ -1975,7 +1978,7 @@ int epi_pf_update(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed,
 
 int epi_debug_step_impl(int cooperative)
 {
-    g_coop = cooperative != 0;
+    g_coop = cooperative < 0 ? 0 : (cooperative > 2 ? 2 : cooperative);
     return EPI_OK;
 }
 

@@ -291,9 +291,11 @@ int epi_pf_collect(epi_ctx *ctx, epi_belief *b, double *loglik, double *ess, uin
  * way.  enable = 0 forces the binary64 expression everywhere (testing aid,
  * process-wide). */
 int epi_debug_screen(int enable);
-/* Two implementations of the Philox-driven step kernel give identical results:
- * cooperative = 1 (default) hands rejected sampler attempts to idle threads of
- * the workgroup, 0 loops per thread.  Testing aid, process-wide. */
+/* Two implementations of the Philox-driven step kernel give identical results: the cooperative one
+ * hands rejected sampler attempts to idle threads of the workgroup, the other loops per thread.
+ * cooperative = 1 (default) picks by state width (cooperative up to H = 15, where its LDS footprint still
+ * leaves four workgroups per CU), 2 forces the cooperative kernel, 0 the per-thread one.  Testing aid,
+ * process-wide. */
 int epi_debug_step_impl(int cooperative);
 /* With timing enabled every filter update brackets its fused step kernel with a
  * pair of HIP events on the context's stream; epi_ctx_timing_read waits for the

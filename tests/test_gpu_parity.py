@@ -434,19 +434,26 @@ def test_step_implementations_and_screens_agree(delay):
 def test_wide_state_retry_queue_overflow_bit_exact():
     """H = 56 infection ages: 112 binomial draws per particle, so a workgroup's rejected first
     attempts exceed the retry queue and the in-thread completion path runs; still bit-exact."""
+    lib = _lib.load()
     pomdp = em.make_pomdp(LOD=5, horizon=56, test_delay=1)
     orc = pyoracle.Oracle(pomdp.to_c())
     n = 3000
-    st = orc.init_normal(n, 10_000.0, 5_000.0, 5)
-    b = _belief(pomdp, st)
-    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
-    _, mu, _ = orc.log_weights(st, 0.3, 0)
+    st0 = orc.init_normal(n, 10_000.0, 5_000.0, 5)
+    _, mu, _ = orc.log_weights(st0, 0.3, 0)
     o = int(np.median(mu))
-    for step in range(3):
-        em.update(upd, b, em.Action(0.3), o)
-        st, info = orc.pf_update(st, 0.3, o, SEED, step)
-        assert upd.last_flags == info["flags"]
-    _eq(b.download(), st)
+    try:
+        for impl in (2, 1):                  # forced cooperative kernel, then the default choice (per-thread at this width)
+            check(lib.epi_debug_step_impl(impl))
+            st = st0
+            b = _belief(pomdp, st)
+            upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+            for step in range(3):
+                em.update(upd, b, em.Action(0.3), o)
+                st, info = orc.pf_update(st, 0.3, o, SEED, step)
+                assert upd.last_flags == info["flags"]
+            _eq(b.download(), st)
+    finally:
+        check(lib.epi_debug_step_impl(1))
 
 
 def test_sharded_filter_over_rccl_single_rank(tmp_path):

@@ -1,0 +1,19 @@
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import epidemicmodeling_amd as em
+from epidemicmodeling_amd import _lib
+lib = _lib.load()
+for H in (14, 28, 56):
+    pomdp = em.make_pomdp(LOD=5, horizon=H)
+    n, T = 4_000_000, 10
+    for impl in (1, 0):
+        lib.epi_debug_step_impl(impl)
+        b = em.random_states(pomdp, n, seed=1)
+        em.rollout_batch(b, 2, 0.2, seed=3, want_hist=False, want_rew=False)
+        t0 = time.perf_counter()
+        em.rollout_batch(b, T, 0.2, seed=2, want_hist=False, want_rew=False)
+        dt = time.perf_counter() - t0
+        print(f"H={H} impl={'coop' if impl else 'per-thread'}: {n*T/dt:.3e} particle-steps/s")
+        b.close()
+lib.epi_debug_step_impl(1)
