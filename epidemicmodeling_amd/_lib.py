@@ -126,6 +126,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("EPI_STEP_IMPL"):            # A/B measurements: 0 per-thread, 1 by state width, 2 cooperative
+        lib.epi_debug_step_impl(int(os.environ["EPI_STEP_IMPL"]))
     _lib = lib
     return lib
 
