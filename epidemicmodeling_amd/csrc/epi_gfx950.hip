@@ -286,6 +286,14 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
     return true;
 }
 
+// The posterior state and the log weights are written once and read by a later kernel: stored with the
+// non-temporal hint so that they do not displace the workgroups' spill lines and the tables from the L2.
+#ifdef EPI_NO_STREAM_HINT
+#define EPI_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define EPI_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 #ifndef EPI_COOP_WAVES
 #define EPI_COOP_WAVES 4   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
                            // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         }
         if constexpr (WEIGH) {
             const double lw = log_weight(tm, tv, A.o);
-            A.lw[m] = lw;
+            EPI_STREAM_STORE(&A.lw[m], lw);
             code = order_code(lw);
         }
     }
@@ -485,12 +493,12 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 else tv = (i >= 1) ? in[(int64_t)tests_row(H, r, i) * is + src] : 0;
                 const int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
                 if (r == 0) { R += ts; Ii -= ts; }
-                else if (i + 1 < H) out[(int64_t)tests_row(H, r - 1, i + 1) * os + m] = ts;
+                else if (i + 1 < H) EPI_STREAM_STORE(&out[(int64_t)tests_row(H, r - 1, i + 1) * os + m], ts);
             }
             if (Ii < 0) flags |= EPI_F_NEG_I;                                      // simulate.jl:117
             o_sum += pos;
             if (it == 0) R += Ii;                                                  // simulate.jl:144
-            else { out[(int64_t)(2 + it) * os + m] = Ii; sum_inf += Ii; }          // simulate.jl:145
+            else { EPI_STREAM_STORE(&out[(int64_t)(2 + it) * os + m], Ii); sum_inf += Ii; }   // simulate.jl:145
             const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78
             float zf = z_odd;
             uint32_t wu = w_odd;
@@ -558,9 +566,9 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
         else newi = (int32_t)__builtin_floor(((double)S / (double)denom) * infsum);             // simulate.jl:42-44
-        out[(int64_t)2 * os + m] = newi;                                                        // simulate.jl:147
-        out[m] = S - newi;                                                                      // simulate.jl:148
-        out[os + m] = R;
+        EPI_STREAM_STORE(&out[(int64_t)2 * os + m], newi);                                      // simulate.jl:147
+        EPI_STREAM_STORE(&out[m], S - newi);                                                    // simulate.jl:148
+        EPI_STREAM_STORE(&out[os + m], R);
         if (Ak->o_out) Ak->o_out[m] = o_sum;
         if (Ak->newinf_out) Ak->newinf_out[m] = newi;
         if (Ak->r_out) {
