@@ -359,7 +359,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         }
         if constexpr (WEIGH) {
             const double lw = log_weight(tm, tv, A.o);
-            EPI_STREAM_STORE(&A.lw[m], lw);
+            EPI_STREAM_STORE(&(A.lw + base)[tid], lw);
             code = order_code(lw);
         }
     }
@@ -493,12 +493,12 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 else tv = (i >= 1) ? in[(int64_t)tests_row(H, r, i) * is + src] : 0;
                 const int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
                 if (r == 0) { R += ts; Ii -= ts; }
-                else if (i + 1 < H) EPI_STREAM_STORE(&out[(int64_t)tests_row(H, r - 1, i + 1) * os + m], ts);
+                else if (i + 1 < H) EPI_STREAM_STORE(&(out + ((int64_t)tests_row(H, r - 1, i + 1) * os + base))[tid], ts);
             }
             if (Ii < 0) flags |= EPI_F_NEG_I;                                      // simulate.jl:117
             o_sum += pos;
             if (it == 0) R += Ii;                                                  // simulate.jl:144
-            else { EPI_STREAM_STORE(&out[(int64_t)(2 + it) * os + m], Ii); sum_inf += Ii; }   // simulate.jl:145
+            else { EPI_STREAM_STORE(&(out + ((int64_t)(2 + it) * os + base))[tid], Ii); sum_inf += Ii; }   // simulate.jl:145
             const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78
             float zf = z_odd;
             uint32_t wu = w_odd;
@@ -566,9 +566,9 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
         else newi = (int32_t)__builtin_floor(((double)S / (double)denom) * infsum);             // simulate.jl:42-44
-        EPI_STREAM_STORE(&out[(int64_t)2 * os + m], newi);                                      // simulate.jl:147
-        EPI_STREAM_STORE(&out[m], S - newi);                                                    // simulate.jl:148
-        EPI_STREAM_STORE(&out[os + m], R);
+        EPI_STREAM_STORE(&(out + ((int64_t)2 * os + base))[tid], newi);                         // simulate.jl:147
+        EPI_STREAM_STORE(&(out + base)[tid], S - newi);                                         // simulate.jl:148
+        EPI_STREAM_STORE(&(out + (os + base))[tid], R);
         if (Ak->o_out) Ak->o_out[m] = o_sum;
         if (Ak->newinf_out) Ak->newinf_out[m] = newi;
         if (Ak->r_out) {
