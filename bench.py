@@ -183,13 +183,13 @@ def main():
         "metric": "particle-steps/sec (whole node) at 10^8 particles; % of HBM roofline",
         "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "int32 counts / f64 sampler arithmetic", "data": "synthetic",
+        "dtype": "f64", "dtype_note": "int32 compartment counts in HBM; sampler and weight arithmetic in binary64", "data": "synthetic",
         "config": {"workload": "bootstrap particle-filter update (predict+weight+systematic resample)",
                    "particles": n, "H": H, "test_delay": D, "N": pomdp.N, "action": ACTION, "seed": SEED,
                    "sharding": f"by index over {args.gpus} rank(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                     "kernel": "k_step<weigh>", "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
+                     "kernel": "k_step_coop<true>", "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
         "diagnostics": diag,
     }
     if args.gpus == 1 and not args.no_cpu:
