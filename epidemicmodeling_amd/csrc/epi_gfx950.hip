@@ -380,12 +380,13 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
             for (int j = 0; j < 2; j++) {
                 const int32_t n = j ? nn.y : nn.x;
                 const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];
-                int32_t x; double pp; bool flip;
-                const int cls = binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
+                int32_t x;
+                const int cls = binom_classify_tab(*Dp, j, i, n, x);
+                const bool flip = Dp->flip[j][i] != 0;
                 bool fail = false;
                 if (cls == BINOM_INVERSION) x = binom_inversion(n, Dp->lnq[j][i], Dp->sr[j][i], wa);
                 else if (cls == BINOM_REJECTION) {
-                    const BtrsConsts C = btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen);
+                    const BtrsConsts C = btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen);
                     x = btrs_attempt(C, wa, wb);
                     fail = x < 0;
                 }
@@ -421,10 +422,8 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14));
                 else {                                                              // queue full: finish here
                     const int32_t n = slot_words[(i * TPB + tid) * 2 + j];
-                    int32_t x; double pp; bool flip;
-                    binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
-                    const int32_t k = btrs_finish(btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
-                    slot_words[(i * TPB + tid) * 2 + j] = flip ? n - k : k;
+                    const int32_t k = btrs_finish(btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
+                    slot_words[(i * TPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
                 }
                 pos++;
             }
@@ -449,9 +448,8 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 const unsigned short entry = q[e];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
                 const int32_t n = slot_words[(i * TPB + t) * 2 + j];
-                int32_t x; double pp; bool flip;
-                binom_classify(n, j ? P.p[i] : P.q[i], x, pp, flip);
-                const BtrsConsts C = btrs_consts(n, pp, Dp->lpq[j][i], Dp->lf, screen);
+                const bool flip = Dp->flip[j][i] != 0;                             // a queued draw is a rejection draw
+                const BtrsConsts C = btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wa, wb;
                 retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);

@@ -41,6 +41,13 @@ struct DevParams {
     double lnq[2][EPI_MAX_H];   // s_log(1 - pp), pp = min(p, 1 - p)
     double sr[2][EPI_MAX_H];    // pp / (1 - pp)
     double lpq[2][EPI_MAX_H];   // s_log(pp / (1 - pp))
+    double pp[2][EPI_MAX_H];    // the folded probability min(p, 1 - p)
+    // binom_classify per bin: kind 0 = the draw is 0 (p <= 0), 1 = the draw is n (p >= 1), 2 = sampled, by
+    // inversion for 0 < n < nthr and by rejection from nthr on; nthr = the smallest n with fl(n pp) >= 10
+    // (2^31 if there is none below 2^31)
+    uint32_t nthr[2][EPI_MAX_H];
+    int32_t kind[2][EPI_MAX_H];
+    int32_t flip[2][EPI_MAX_H]; // p > 1/2: the draw is n - Binomial(n, 1 - p)
     LfTable lf;                 // tabulated log factorials (device memory; null on the host)
 };
 
@@ -54,19 +61,42 @@ __host__ __device__ inline void derive_params(DevParams& D)
             D.lnq[j][i] = ok ? s_log(1.0 - pp) : 0.0;
             D.sr[j][i] = ok ? pp / (1.0 - pp) : 0.0;
             D.lpq[j][i] = ok ? s_log(pp / (1.0 - pp)) : 0.0;
+            D.pp[j][i] = pp;
+            D.kind[j][i] = !(p > 0.0) ? 0 : (p >= 1.0 ? 1 : 2);
+            D.flip[j][i] = p > 0.5 && p < 1.0;                          // only sampled draws are folded
+            uint32_t thr = 0x80000000u;
+            if (ok && 10.0 / pp < 2147483648.0) {
+                int64_t t = (int64_t)(10.0 / pp);
+                if (t < 1) t = 1;
+                while (t > 1 && !((double)(t - 1) * pp < 10.0)) t--;        // the product is monotone in t: exact search
+                while (t < 2147483648LL && (double)t * pp < 10.0) t++;
+                thr = (uint32_t)t;
+            }
+            D.nthr[j][i] = thr;
         }
+}
+
+// binom_classify from the per-bin tables (identical decisions)
+__host__ __device__ __forceinline__ int binom_classify_tab(const DevParams& D, int j, int bin, int32_t n, int32_t& result)
+{
+    result = 0;
+    const int kind = D.kind[j][bin];
+    if (n <= 0 || kind == 0) return BINOM_DONE;
+    if (kind == 1) { result = n; return BINOM_DONE; }
+    return (uint32_t)n < D.nthr[j][bin] ? BINOM_INVERSION : BINOM_REJECTION;
 }
 
 // One binomial draw of a bin (j = 0 isolation, 1 positive test) from its attempt-0 word pair.
 __device__ __forceinline__ int32_t bin_binomial(const DevParams& D, int bin, int j, int32_t n, uint32_t fa, uint32_t fb,
                                                 const Rng& g, bool screen)
 {
-    int32_t x; double pp; bool flip;
-    const int cls = binom_classify(n, j ? D.P.p[bin] : D.P.q[bin], x, pp, flip);
+    int32_t x;
+    const int cls = binom_classify_tab(D, j, bin, n, x);
     if (cls == BINOM_DONE) return x;
+    const bool flip = D.flip[j][bin] != 0;
     if (cls == BINOM_INVERSION) x = binom_inversion(n, D.lnq[j][bin], D.sr[j][bin], fa);
     else {
-        const BtrsConsts C = btrs_consts(n, pp, D.lpq[j][bin], D.lf, screen);
+        const BtrsConsts C = btrs_consts(n, D.pp[j][bin], D.lpq[j][bin], D.lf, screen);
         x = btrs_attempt(C, fa, fb);
         if (x < 0) x = btrs_finish(C, g, j ? K_POS : K_SYMPT, (uint32_t)bin, 1u);
     }

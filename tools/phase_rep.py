@@ -40,9 +40,11 @@ def phase_A(s):
 
 
 def phase_B(s):
-    s = sub(s, '#pragma unroll 1\n    for (int i = 0; i < H; i++) {\n        bool fail0 = false, fail1 = false;', REP + '#pragma unroll 1\n    for (int i = 0; i < H; i++) {\n        bool fail0 = false, fail1 = false;')
-    s = sub(s, '            slots[i * TPB + tid] = nn;\n        }\n        const unsigned short e0', '            if (last) slots[i * TPB + tid] = nn;\n        }\n        fail0 = fail0 && last; fail1 = fail1 && last;\n        const unsigned short e0')
-    s = sub(s, '    // ---- C: binomial retry rounds', '    }\n    // ---- C: binomial retry rounds')
+    s = sub(s, '    unsigned long long fm0 = 0ULL, fm1 = 0ULL;                                     // bins 0..31 / 32..63\n#pragma unroll 1\n    for (int i = 0; i < H; i++) {\n        if (active) {',
+            '    unsigned long long fm0 = 0ULL, fm1 = 0ULL;\n    ' + REP + '#pragma unroll 1\n    for (int i = 0; i < H; i++) {\n        if (active) {')
+    s = sub(s, '            slots[i * TPB + tid] = nn;\n            if (i < 32) fm0 |=', '            if (last) slots[i * TPB + tid] = nn; else failbits = 0u;\n            if (i < 32) fm0 |=')
+    s = sub(s, '    {\n        const int lane = tid & 63;\n        const unsigned int mine = (unsigned int)(__popcll(fm0) + __popcll(fm1));',
+            '    }\n    {\n        const int lane = tid & 63;\n        const unsigned int mine = (unsigned int)(__popcll(fm0) + __popcll(fm1));')
     return s
 
 
