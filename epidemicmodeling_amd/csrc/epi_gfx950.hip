@@ -2,21 +2,27 @@
 // bootstrap particle-filter update on gfx950 (MI355X), and the C ABI of
 // include/epi.h on top of them.
 //
-// Kernels (all one thread per particle or per output slot, 256-thread
-// workgroups = 4 wave64, coalesced struct-of-arrays rows):
-//   k_step        fused [gather by ancestor] + observation weight + SimStep
+// Kernels (one thread per particle or per output slot, 256-thread workgroups =
+// 4 wave64, coalesced struct-of-arrays rows):
+//   k_step_coop   fused [gather by ancestor] + observation weight + SimStep, phase
+//                 by phase over a workgroup with rejected sampler attempts queued
+//                 in LDS (states up to H = 15)
+//   k_step        the same step with every rejection loop in its own thread (wide
+//                 states, injected / recorded variates)
 //   k_wsum        fixed-point weights: per-workgroup totals
 //   k_wscan       single-workgroup exclusive scan of those totals
 //   k_wcum        fixed-point weights again + workgroup prefix scan -> C[i]
 //   k_scatter     systematic resampling from the ancestors' side: every particle
 //                 writes its index into the contiguous output slots it owns
 //                 (k_scatter_big: the long ranges of collapsed weights)
-//   k_export / k_import / k_gather   move resampled particles
-//   k_sums        integer column sums (belief mean)
-//   k_init_*      initial particles
+//   k_export / k_import / k_gather / k_replicate   move resampled particles
+//   k_sums, k_suminf, k_qsel_hist   belief mean and order statistics
+//   k_score_acc / k_score_mean      discounted reward of scenario rollouts
+//   k_ode_loss / k_sum_partials     ODE-model loss of an ensemble kept on the device
+//   k_init_*      initial particles;  k_lfact_fill  the log-factorial table
 //
 // The filter keeps the posterior as (propagated particles, ancestor index):
-// the gather of resampled particles is folded into the next k_step, so one
+// the gather of resampled particles is folded into the next step kernel, so one
 // update reads each prior particle once and writes each posterior particle
 // once.
 #include <hip/hip_runtime.h>
