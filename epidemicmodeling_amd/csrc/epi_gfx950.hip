@@ -359,8 +359,10 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
             if constexpr (WEIGH) {
                 const double pi = P.p[i];
                 tm += ntf * pi;                                                    // POMDPsInterface.jl:19
-                const double sd = __builtin_sqrt(ntf * pi * (1.0 - pi));
-                tv += sd * sd;                                                     // POMDPsInterface.jl:20
+                if (pi > 0.0 && pi < 1.0) {                                        // else std = 0 exactly: nothing to add
+                    const double sd = __builtin_sqrt(ntf * pi * (1.0 - pi));
+                    tv += sd * sd;                                                 // POMDPsInterface.jl:20
+                }
             }
         }
         if constexpr (WEIGH) {
