@@ -151,6 +151,9 @@ class ShardedFilter:
             raise ValueError("fewer particles than ranks")
         self.shard = shard if shard is not None else LibShard(pomdp, self.n_local, self.n_total, self.slot0, device)
         self.comm_device = self.shard.comm_device
+        # the gloo backend moves host memory only: device tensors are staged through the host around each call
+        # (rehearsals of the multi-rank path on a machine with fewer GPUs than ranks; RCCL takes them directly)
+        self.stage = dist.get_backend() == "gloo" and torch.device(self.comm_device).type == "cuda"
         self.step = 0
         self.frac_bits = _frac_bits(self.n_total)
 
@@ -170,6 +173,23 @@ class ShardedFilter:
     def timing_read(self):
         return self.shard.timing_read()
 
+    # -- collectives (staged through the host for gloo) ---------------------
+    def _all_reduce(self, t, op):
+        if not self.stage:
+            self.dist.all_reduce(t, op=op)
+            return
+        h = t.cpu()
+        self.dist.all_reduce(h, op=op)
+        t.copy_(h)
+
+    def _all_gather(self, out, mine):
+        if not self.stage:
+            self.dist.all_gather_into_tensor(out, mine)
+            return
+        h = self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(h, mine.cpu())
+        out.copy_(h)
+
     # -- update -------------------------------------------------------------
     def update(self, a: float, o: int) -> dict:
         torch, dist = self.torch, self.dist
@@ -180,20 +200,20 @@ class ShardedFilter:
             # 1-4 without a host round trip: the library's kernels and the collectives are ordered on one stream
             t = torch.empty(1, dtype=torch.float64, device=self.comm_device)
             sh.predict_dev(a, o, seed, step, t)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self._all_reduce(t, dist.ReduceOp.MAX)
             mine = torch.empty(4, dtype=torch.float64, device=self.comm_device)
             sh.weigh_dev(t, mine)
         else:
             # 1-2: fused weight + step, global maximum log weight
             t = torch.tensor([sh.predict(a, o, seed, step)], dtype=torch.float64, device=self.comm_device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self._all_reduce(t, dist.ReduceOp.MAX)
             lwmax = t.item()
             # 3-4: local fixed-point weights, totals of every shard
             w_local, sq_local, fl_local = sh.weigh(lwmax)
             # totals are < 2^53 and flags < 2^32: exact as doubles
             mine = torch.tensor([float(w_local), sq_local, float(fl_local), lwmax], dtype=torch.float64, device=self.comm_device)
         allv = torch.empty(4 * G, dtype=torch.float64, device=self.comm_device)
-        dist.all_gather_into_tensor(allv, mine)
+        self._all_gather(allv, mine)
         allv = allv.cpu().tolist()                                         # the update's one wait for the device
         w_shard = [int(allv[4 * h]) for h in range(G)]
         sumsq = math.fsum(allv[4 * h + 1] for h in range(G))
@@ -211,17 +231,18 @@ class ShardedFilter:
                 continue
             s0, s1 = max(lo[g], st[h]), min(lo[g + 1], st[h + 1])          # my particles -> slots of rank h
             if s1 > s0:
-                ops.append(dist.P2POp(dist.isend, sh.export(g, w_shard, seed, step, s0, s1), h))
+                blk = sh.export(g, w_shard, seed, step, s0, s1)
+                ops.append(dist.P2POp(dist.isend, blk.cpu() if self.stage else blk, h))
             r0, r1 = max(lo[h], st[g]), min(lo[h + 1], st[g + 1])          # rank h's particles -> my slots
             if r1 > r0:
                 buf = sh.recv_buffer(r1 - r0)
-                recvs.append((r0, r1, buf))
-                ops.append(dist.P2POp(dist.irecv, buf, h))
+                recvs.append((r0, r1, buf.cpu() if self.stage else buf))
+                ops.append(dist.P2POp(dist.irecv, recvs[-1][2], h))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         for r0, r1, buf in recvs:
-            sh.import_(r0, r1, buf)
+            sh.import_(r0, r1, buf.to(self.comm_device) if self.stage else buf)
         s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
         if s1 > s0:
             sh.select_local(g, w_shard, seed, step, s0, s1)
@@ -243,7 +264,7 @@ class ShardedFilter:
         integer sums added over ranks, then rounded once."""
         torch, dist = self.torch, self.dist
         sums = torch.from_numpy(self.shard.sums()).to(self.comm_device)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        self._all_reduce(sums, dist.ReduceOp.SUM)
         sums = sums.cpu().numpy()
         p = self.pomdp
         H, D1 = p.horizon, p.test_delay + 1
