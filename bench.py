@@ -117,9 +117,15 @@ def run_sharded(args):
     if "RANK" not in os.environ:          # --sharded on one GPU without a launcher: a group of one
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    # EPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # tensors are staged through the host); the measured configuration is nccl (RCCL), one GPU per rank
+    backend = os.environ.get("EPI_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     pomdp = em.make_pomdp()
     n = args.particles
     obs = observations(pomdp, args.warmup + args.steps) if rank == 0 else None
@@ -140,7 +146,7 @@ def run_sharded(args):
     dist.barrier()
     dt = time.perf_counter() - t0
     ksum, kcnt = f.timing_read()
-    tt = torch.tensor([dt, ksum / max(kcnt, 1)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt, ksum / max(kcnt, 1)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, kms = float(tt[0]), float(tt[1])
     dist.destroy_process_group()
