@@ -674,3 +674,42 @@ def test_config5_wide_state_ensemble():
             tot = arr.sum(axis=0)
             assert arr.shape == (3, T, n) and (tot[0] == pomdp.N).all()
         ens.close()
+
+
+# ---------------------------------------------------------------------------
+# randomised parameter sets: shapes, delays and probabilities at the edges of every sampler regime
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(12))
+def test_random_parameter_sets_bit_exact(seed):
+    rng = np.random.default_rng(1000 + seed)
+    H = int(rng.choice([1, 2, 3, 7, 14, 15, 16, 21]))
+    D = int(rng.integers(0, 8))
+    N = int(rng.choice([50, 5_000, 1_000_000, 300_000_000]))
+    p = rng.random(H)
+    p[rng.random(H) < 0.2] = 0.0
+    p[rng.random(H) < 0.15] = 1.0
+    p[rng.random(H) < 0.2] *= 1e-4                                   # inversion regime
+    shapes = 10.0 ** rng.uniform(-6, 1, H)
+    shapes[rng.random(H) < 0.2] = 0.0
+    scales = 10.0 ** rng.uniform(-3, 0.5, H)
+    pomdp = em.make_pomdp(horizon=H, test_delay=D, N=N, pos_test_probs=list(p), Infdistributions=list(zip(shapes, scales)),
+                          symptomatic_isolation_prob=float(rng.random()), asymptomatic_prob=float(rng.random()))
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 1500
+    st = random_states(pomdp, n, rng, scale=max(1, N // (4 * H + 10)))
+    a = float(rng.random())
+    b = _belief(pomdp, st)
+    # plain steps (per-particle outputs) ...
+    o, r, fl = em.step_batch(b, a, seed=5, step=1)
+    exp, eo, er, _, efl = orc.step_batch(st, a, 0.0, seed=5, step=1)
+    _eq(b.download(), exp)
+    assert (o == eo).all() and fl == efl and (r.view(np.uint64) == er.view(np.uint64)).all()
+    # ... and filter updates on top
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    _, mu, _ = orc.log_weights(exp, a, 0)
+    obs = int(np.median(mu))
+    for step in range(2):
+        em.update(upd, b, em.Action(a), obs)
+        exp, info = orc.pf_update(exp, a, obs, SEED, step)
+        assert upd.last_flags == info["flags"]
+    _eq(b.download(), exp)
