@@ -846,6 +846,69 @@ __global__ __launch_bounds__(TPB) void k_scatter(int64_t n_local, const unsigned
     }
 }
 
+// k_wcum and k_scatter in one pass for a population held by one device (slot m = particle m before resampling,
+// no shard offset): the cumulative weights stay in registers and are never written.
+__global__ __launch_bounds__(TPB) void k_wcum_scatter(int64_t n, const double* __restrict__ lw, const DevScalars* __restrict__ scal, int F,
+                                                       const unsigned long long* __restrict__ blockoff, double u,
+                                                       int32_t* __restrict__ anc, unsigned long long* __restrict__ big_count, BigRange* __restrict__ big)
+{
+    __shared__ unsigned long long s_w[TPB / 64];
+    const double lwmax = scal->lwmax;
+    const double scale = u2d((uint64_t)(F + 1023) << 52);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long v[SCAN_ITEMS];
+    unsigned long long run = 0ULL;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        int64_t i = base + j;
+        unsigned long long w = (i < n) ? quantize(lw[i], lwmax, scale) : 0ULL;
+        run += w;
+        v[j] = run;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long incl = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = shfl_up_u64(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long off = blockoff[blockIdx.x] + (incl - run);
+    for (int w = 0; w < wv; w++) off += s_w[w];
+    const unsigned long long W = scal->w_local;             // the total: k_wscan has run
+    if (W == 0ULL) {                                        // every weight zero: keep the particles in place
+        for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) anc[base + j] = (int32_t)(base + j);
+        return;
+    }
+    const double stepw = (double)W / (double)n;
+    const double inv_stepw = (double)n / (double)W;
+    int64_t a = base == 0 ? 0 : first_slot(off, stepw, inv_stepw, u, n);
+    a = a > n ? n : a;
+#pragma unroll 1
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const int64_t i = base + j;
+        int64_t b = a;
+        if (i < n) b = i == n - 1 ? n : first_slot(off + v[j], stepw, inv_stepw, u, n);
+        const int64_t len = b - a;
+        if (len > 0 && len <= SMALL_RANGE)
+            for (int64_t k = 0; k < len; k++) anc[a + k] = (int32_t)i;
+        unsigned long long mask = __ballot(len > SMALL_RANGE && len <= BIG_RANGE);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ULL;
+            const int64_t a_l = (int64_t)__shfl((unsigned int)(a >> 32), l, 64) << 32 | (int64_t)__shfl((unsigned int)a, l, 64);
+            const int len_l = __shfl((int)len, l, 64);
+            const int idx_l = __shfl((int)i, l, 64);
+            for (int k = lane; k < len_l; k += 64) anc[a_l + k] = idx_l;
+        }
+        if (len > BIG_RANGE) {
+            const unsigned long long pos = atomicAdd(big_count, 1ULL);
+            big[pos] = BigRange{(long long)a, (long long)b, (long long)i};
+        }
+        a = b;
+    }
+}
+
 // the listed long ranges, each spread over the whole grid
 __global__ __launch_bounds__(TPB) void k_scatter_big(const unsigned long long* __restrict__ big_count, const BigRange* __restrict__ big,
                                                       int64_t slot0, int32_t* __restrict__ anc)
@@ -1959,12 +2022,18 @@ int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t
     rc = launch_predict(c, b, a, o, seed, step);
     if (rc) return rc;
     k_scal_lwmax_local<<<1, 1, 0, c->stream>>>(c->d_scal);
-    rc = launch_weigh(c, b);
-    if (rc) return rc;
-    k_scal_total_local<<<1, 1, 0, c->stream>>>(c->d_scal);
     const double u = resample_offset(seed, step);
-    rc = launch_scatter(c, b, u, 0, b->n);
-    if (rc) return rc;
+    // weights -> tile totals -> scan of the totals -> cumulative weights and ancestors in one pass
+    HIPCHECK(hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream));
+    BigRange* list = reinterpret_cast<BigRange*>(b->big + 2);
+    k_wsum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum, b->blocksq);
+    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, c->d_scal);
+    k_scal_total_local<<<1, 1, 0, c->stream>>>(c->d_scal);
+    k_wcum_scatter<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum, u, b->anc, b->big, list);
+    int64_t gx = ceil_div(b->n, (int64_t)TPB * 8);
+    gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+    k_scatter_big<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(b->big, list, 0, b->anc);
+    HIPCHECK(hipGetLastError());
     b->cur ^= 1; b->has_anc = true;
     return EPI_OK;
 }
