@@ -353,13 +353,30 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
 #define GAMMA_MAX_ATTEMPTS 512u
 #define GAMMA_MIN_SHAPE 0x1p-30
 
+/* c >= 1/sqrt(9 d) within 3e-10: three Newton steps for the reciprocal square root from the bit-shift seed   */
+/* (the iterates stay below the root) and a factor 1 + 2^-32.  The rejection is exact for every such c: the     */
+/* normal envelope dominates d (log v - v + 1) as soon as 9 d c^2 >= 1, and d v is Gamma(d + 1/3) whatever c.  */
+static inline double gamma_c(double d)
+{
+    const double h = 4.5 * d;
+    double x9 = 9.0 * d, y;
+    uint64_t b;
+    memcpy(&b, &x9, 8);
+    b = 0x5FE6EB50C7B537A9ULL - (b >> 1);
+    memcpy(&y, &b, 8);
+    y = y * (1.5 - h * (y * y));
+    y = y * (1.5 - h * (y * y));
+    y = y * (1.5 - h * (y * y));
+    return y * 1.00000000023283064365386962890625;
+}
+
 static double gamma_draw(double shape, double scale, const rng_t *g, uint32_t bin)
 {
     if (!(shape >= GAMMA_MIN_SHAPE)) return 0.0;
     int boost = shape < 1.0;
     double al = boost ? shape + 1.0 : shape;
     double d = al - 0.3333333333333333;
-    double c = 1.0 / sqrt(9.0 * d);
+    double c = gamma_c(d);
     double v = 1.0;
     uint32_t w[4];
     for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
