@@ -5,7 +5,7 @@ weight + systematic resample) on MI355X.
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one belief update of the whole particle population.  The population
-is 10^8 particles (the size BASELINE.json's metric is quoted at) for every N:
+is 10^8 particles (the size the headline metric is quoted at) for every N:
 sharded by index over the N ranks (strong scaling).  Inputs are synthetic and
 generated on the device before the timed region; the timed region holds K
 updates between barriers + device synchronisation, max over ranks.
