@@ -49,14 +49,20 @@ def observations(pomdp, count):
     return obs
 
 
-def cpu_baseline(pomdp, seconds_target=12.0):
+_OMP_DEFAULT = None
+
+
+def cpu_baseline(pomdp, seconds_target=12.0, threads=None, n=500_000):
     """The oracle's complete update (port of the reference algorithm, OpenMP) on a bounded sample."""
     import numpy as np
     from oracle import pyoracle
     orc = pyoracle.Oracle(pomdp.to_c())
     L = pyoracle.lib()
-    threads = L.orc_max_threads()
-    n = 500_000
+    global _OMP_DEFAULT
+    if _OMP_DEFAULT is None:
+        _OMP_DEFAULT = L.orc_max_threads()          # OMP_NUM_THREADS of this host, before any override
+    threads = threads or _OMP_DEFAULT
+    L.orc_set_threads(threads)
     st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
     _, mu, _ = orc.log_weights(st, ACTION, 0)
     o = int(np.median(mu))
@@ -199,6 +205,7 @@ def main():
         "diagnostics": diag,
     }
     if args.gpus == 1 and not args.no_cpu:
+        out["cpu_baseline_single_thread"] = cpu_baseline(pomdp, seconds_target=4.0, threads=1, n=100_000)
         out["cpu_baseline"] = cpu_baseline(pomdp)
     print(json.dumps(out))
 
