@@ -713,3 +713,43 @@ def test_random_parameter_sets_bit_exact(seed):
         exp, info = orc.pf_update(exp, a, obs, SEED, step)
         assert upd.last_flags == info["flags"]
     _eq(b.download(), exp)
+
+
+# ---------------------------------------------------------------------------
+# the device samplers against the closed-form distributions, at a sample size the CPU suite does not reach
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,p", [(17_000, 0.035), (3_400, 0.56), (2_300, 0.0014), (4_800, 0.0049), (1_000_000, 0.3), (40, 0.5)])
+def test_device_binomial_distribution(n, p):
+    """4 10^6 draws per case from the device sampler (the parameter regimes of the default model among them):
+    chi-square against the Binomial pmf and the mean within five standard errors."""
+    from scipy import stats
+    pomdp = em.make_pomdp(LOD=5)
+    ctx = em.interface.context_for(pomdp)
+    cnt = 4_000_000
+    nn = np.full(cnt, n, dtype=np.int64)
+    pp = np.full(cnt, p)
+    out = np.empty(cnt, np.int64)
+    check(ctx.lib.epi_sample_binomial(ctx.handle, cnt, as_i64p(nn), as_f64p(pp), 777, 1, 2, 0, as_i64p(out)))
+    assert out.min() >= 0 and out.max() <= n
+    width = max(1, int(np.sqrt(n * p * (1 - p)) / 8))
+    lo, hi = int(out.min()), int(out.max())
+    edges = np.arange(lo, hi + width + 1, width)
+    obs = np.histogram(out, bins=edges)[0].astype(float)
+    exp = (stats.binom.cdf(edges[1:] - 1, n, p) - stats.binom.cdf(edges[:-1] - 1, n, p)) * cnt
+    m = exp >= 10
+    chi = ((obs[m] - exp[m]) ** 2 / exp[m]).sum()
+    assert stats.chi2.sf(chi, int(m.sum())) > 1e-5, (n, p, chi, int(m.sum()))
+    assert abs(out.mean() - n * p) < 5 * np.sqrt(n * p * (1 - p) / cnt)
+
+
+@pytest.mark.parametrize("k,th", [(341.0, 0.0465), (40_000.0, 0.122), (1.6, 0.21), (0.35, 0.16), (3.0e6, 1.0)])
+def test_device_gamma_distribution(k, th):
+    from scipy import stats
+    pomdp = em.make_pomdp(LOD=5)
+    ctx = em.interface.context_for(pomdp)
+    cnt = 2_000_000
+    out = np.empty(cnt)
+    check(ctx.lib.epi_sample_gamma(ctx.handle, cnt, as_f64p(np.full(cnt, k)), as_f64p(np.full(cnt, th)), 4242, 3, 9, as_f64p(out)))
+    assert (out > 0).all()
+    assert stats.kstest(out, "gamma", args=(k, 0, th)).pvalue > 1e-5
+    assert abs(out.mean() - k * th) < 5 * th * np.sqrt(k / cnt)
