@@ -753,3 +753,102 @@ def test_device_gamma_distribution(k, th):
     assert (out > 0).all()
     assert stats.kstest(out, "gamma", args=(k, 0, th)).pvalue > 1e-5
     assert abs(out.mean() - k * th) < 5 * th * np.sqrt(k / cnt)
+
+
+# ---------------------------------------------------------------------------
+# the whole step against an independent sampler stack (numpy's Binomial / Gamma generators driving the numpy
+# transliteration of the Julia step): the kind of agreement that is possible with a native RNG
+# ---------------------------------------------------------------------------
+def test_trajectory_distributions_match_native_rng_simulation():
+    from scipy import stats
+    from oracle import step_numpy as sn
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    cp = pomdp.to_c()
+    H, D = pomdp.horizon, pomdp.test_delay
+    q, p = np.array(cp.q[:H]), np.array(cp.p[:H])
+    k, th = np.array(cp.k[:H]), np.array(cp.theta[:H])
+    a, T, n = 0.3, 8, 4000
+    s0 = em.State_from([3000] * H, pomdp)
+    # device: n trajectories from the same start state
+    st = (np.full(n, s0.S), np.tile(s0.I, (n, 1)), np.full(n, s0.R), np.zeros((n, H, D + 1), dtype=np.int64))
+    b = _belief(pomdp, st)
+    hist, _, fl = em.rollout_batch(b, T, a, seed=2024, want_rew=False)
+    dS, dI, dR, _ = b.download()
+    dev = {"S": dS, "I": dI.sum(axis=1), "R": dR, "pos": hist[:, :, 3].sum(axis=1)}
+    # numpy's own generators through the transliterated step
+    rng = np.random.default_rng(7)
+    ref = {key: np.empty(n, dtype=np.int64) for key in dev}
+    for m in range(n):
+        S, I, R, tests, tot = int(s0.S), s0.I.copy(), int(s0.R), np.zeros((D + 1, H), dtype=np.int64), 0
+        for _ in range(T):
+            sympt = rng.binomial(I, q)                                     # simulate.jl:58
+            pos = rng.binomial(sn.num_tested(I, tests, a), p)              # simulate.jl:79
+            I2, _, _, _ = sn.update_isolations(I, R, tests, sympt, pos)
+            shape = k * np.roll(I2, 1)                                     # simulate.jl:145, init.jl:71-78
+            gam = np.where(shape > 0, rng.gamma(np.maximum(shape, 1e-300), th), 0.0)
+            S, I, R, tests, _, _ = sn.sim_step(S, I, R, tests, a, pomdp.N, sympt, pos, gam)
+            tot += int(pos.sum())
+        ref["S"][m], ref["I"][m], ref["R"][m], ref["pos"][m] = S, int(I.sum()), R, tot
+    assert fl == 0
+    for key in dev:
+        x, y = dev[key].astype(float), ref[key].astype(float)
+        assert stats.ks_2samp(x, y).pvalue > 1e-4, key
+        se = np.sqrt(x.var() / n + y.var() / n)
+        assert abs(x.mean() - y.mean()) < 5 * se, (key, x.mean(), y.mean(), se)
+
+
+def test_posterior_moments_match_native_rng_filter():
+    """Bootstrap filters with numpy's generators (predict through the transliterated step, Normal observation weight
+    from the pre-step state, systematic resampling) against the device filter: the posterior mean of the infected
+    total after four updates, over independent runs of both, has the same distribution."""
+    from scipy import stats
+    from oracle import step_numpy as sn
+    pomdp = em.make_pomdp(LOD=5)
+    cp = pomdp.to_c()
+    H = pomdp.horizon
+    q, p = np.array(cp.q[:H]), np.array(cp.p[:H])
+    k, th = np.array(cp.k[:H]), np.array(cp.theta[:H])
+    a, T, n, runs = 0.25, 4, 1200, 20
+    obs = [5200, 5000, 4900, 4700]
+    zeros = np.zeros((1, H), dtype=np.int64)
+
+    def native_run(rng):
+        x = rng.normal(10_000.0, 5_000.0, size=(n, H))
+        while (x < 0).any():                                           # truncated, not clipped (src/typedef.jl:163)
+            x[x < 0] = rng.normal(10_000.0, 5_000.0, size=int((x < 0).sum()))
+        I = np.rint(x).astype(np.int64)
+        S = pomdp.N - I.sum(axis=1)
+        R = np.zeros(n, dtype=np.int64)
+        for o in obs:
+            nt = np.floor(I * a)
+            mu = (nt * p).sum(axis=1)
+            var = (np.sqrt(nt * p * (1 - p)) ** 2).sum(axis=1)
+            lw = -0.5 * (o - mu) ** 2 / var - 0.5 * np.log(var)
+            S2, I2, R2 = np.empty_like(S), np.empty_like(I), np.empty_like(R)
+            for m in range(n):
+                sympt = rng.binomial(I[m], q)
+                pos = rng.binomial(nt[m].astype(np.int64), p)
+                Iu, _, _, _ = sn.update_isolations(I[m], int(R[m]), zeros, sympt, pos)
+                shape = k * np.roll(Iu, 1)
+                gam = np.where(shape > 0, rng.gamma(np.maximum(shape, 1e-300), th), 0.0)
+                S2[m], I2[m], R2[m], _, _, _ = sn.sim_step(int(S[m]), I[m], int(R[m]), zeros, a, pomdp.N, sympt, pos, gam)
+            w = np.exp(lw - lw.max())
+            c = np.cumsum(w)
+            pos_u = (np.arange(n) + rng.random()) * (c[-1] / n)
+            anc = np.minimum(np.searchsorted(c, pos_u, side="right"), n - 1)
+            S, I, R = S2[anc], I2[anc], R2[anc]
+        return I.sum(axis=1).mean()
+
+    def device_run(seed):
+        b = em.initialbelief(pomdp, n, seed=seed)
+        upd = em.BootstrapFilter(pomdp, n, seed=seed)
+        for o in obs:
+            em.update(upd, b, em.Action(a), o)
+        m = em.mean(b)
+        b.close()
+        return float(m.I.sum())
+
+    nat = np.array([native_run(np.random.default_rng(100 + r)) for r in range(runs)])
+    dev = np.array([device_run(9000 + r) for r in range(runs)])
+    assert stats.ks_2samp(nat, dev).pvalue > 1e-3, (nat.mean(), dev.mean())
+    assert stats.ttest_ind(nat, dev, equal_var=False).pvalue > 1e-3, (nat.mean(), dev.mean(), nat.std(), dev.std())
