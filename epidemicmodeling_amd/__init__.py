@@ -7,6 +7,7 @@ from .interface import (Context, ParticleCollection, BootstrapFilter, update, ge
                         random_states, mean, suminf_quantiles, BeliefSummary, n_particles, particles, rand, step_batch, rollout_batch, rollout_score, RandomShootingPlanner, SimHist,
                         Simulate, SimulateEnsemble, SimulateClosedLoop)
 from .odefit import Ensemble, FitRandEnsemble, FitRandControlledEnsemble
+from .paramfit import FitInfectionDistributions, prop_above_LOD, CovidPOMDP_generated, CovidPOMDP_from_csv
 
 __all__ = [
     "Action", "State", "CovidPOMDP", "make_pomdp", "unity_test_period", "population", "Array", "State_from",
@@ -14,4 +15,5 @@ __all__ = [
     "initialbelief", "random_states", "mean", "suminf_quantiles", "BeliefSummary", "n_particles", "particles", "rand", "step_batch", "rollout_batch", "rollout_score", "RandomShootingPlanner",
     "SimHist", "Simulate", "SimulateEnsemble", "SimulateClosedLoop",
     "Ensemble", "FitRandEnsemble", "FitRandControlledEnsemble",
+    "FitInfectionDistributions", "prop_above_LOD", "CovidPOMDP_generated", "CovidPOMDP_from_csv",
 ]
