@@ -101,6 +101,7 @@ SIGNATURES = {
     "epi_pf_collect": (C.c_int, [_vp, _vp, _f64p, _f64p, _u32p]),
     "epi_debug_screen": (C.c_int, [C.c_int]),
     "epi_debug_step_impl": (C.c_int, [C.c_int]),
+    "epi_debug_f32_forms": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]),
     "epi_ctx_timing": (C.c_int, [_vp, C.c_int]),
     "epi_ctx_timing_read": (C.c_int, [_vp, _f64p, _i64p]),
     "epi_last_predict_ms": (C.c_float, [_vp]),

@@ -2068,6 +2068,41 @@ int epi_debug_step_impl(int cooperative)
     return EPI_OK;
 }
 
+// epi_debug_f32_forms: the short device forms of the binary32 square root and quotient against the compiler's
+// full expansions, over a run of consecutive bit patterns.
+__global__ __launch_bounds__(256) void k_f32_forms(int mode, uint32_t first_bits, unsigned long long count, unsigned long long* mismatches)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256) {
+        const float x = u2f(first_bits + (uint32_t)i);
+        float got, want;
+        if (mode == 0) { got = sqrt_rn(x); want = __builtin_sqrtf(x); }
+        else if (mode == 1) { got = div_rn(1.0f, x); want = 1.0f / x; }
+        else { const float f = x - 1.0f; got = div_rn(f, 2.0f + f); want = f / (2.0f + f); }
+        bad += f2u(got) != f2u(want);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+int epi_debug_f32_forms(epi_ctx* c, int mode, float first, float last, uint64_t* mismatches)
+{
+    if (!c || !mismatches || mode < 0 || mode > 2 || !(first > 0.0f) || !(last >= first) || !(last < INFINITY))
+        return fail(EPI_EINVAL, "epi_debug_f32_forms: bad argument");
+    HIPCHECK(hipSetDevice(c->device));
+    DevBuf d;
+    if (d.alloc(sizeof(unsigned long long)) != hipSuccess) return fail(EPI_ENOMEM, "epi_debug_f32_forms: hipMalloc failed");
+    HIPCHECK(hipMemsetAsync(d.p, 0, sizeof(unsigned long long), c->stream));
+    const uint32_t b0 = f2u(first);
+    const unsigned long long count = (unsigned long long)(f2u(last) - b0) + 1ull;      // positive floats order like their bits
+    hipLaunchKernelGGL(k_f32_forms, dim3(4096), dim3(256), 0, c->stream, mode, b0, count, (unsigned long long*)d.p);
+    HIPCHECK(hipGetLastError());
+    unsigned long long h = 0;
+    HIPCHECK(hipMemcpyAsync(&h, d.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    *mismatches = h;
+    return EPI_OK;
+}
+
 int epi_debug_screen(int enable)
 {
     g_screen = enable != 0;

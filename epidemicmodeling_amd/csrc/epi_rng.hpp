@@ -79,6 +79,39 @@ EPI_HD double u01(uint32_t w) { return ((double)w + 0.5) * 0x1p-32; }
 
 // ---- elementary functions ---------------------------------------------------
 
+// Correctly rounded binary32 square root and quotient (the values sqrtf and "/" give on the host).  The device
+// forms are the compiler's own expansions (hardware estimate, accurate to one ulp, plus the rounding correction)
+// without the operand scaling and the special-case fix-up that only subnormal, huge or non-finite operands need:
+// every call site keeps its operands between 2^-30 and 2^32 (or exactly zero, which both forms map to zero).
+// EPI_PLAIN_F32 restores the compiler's expansions; the kernel results are the same bits either way.
+EPI_HD float sqrt_rn(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EPI_PLAIN_F32)
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float lo = u2f(f2u(r) - 1u), hi = u2f(f2u(r) + 1u);
+    const float el = __builtin_fmaf(-lo, r, x), eh = __builtin_fmaf(-hi, r, x);
+    float y = el <= 0.0f ? lo : r;
+    y = eh > 0.0f ? hi : y;
+    return y;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+
+EPI_HD float div_rn(float n, float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EPI_PLAIN_F32)
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return q;
+#else
+    return n / d;
+#endif
+}
+
 // natural log, x > 0 finite normal; argument reduction to [sqrt(1/2), sqrt(2))
 // and the degree-14 series in s = f/(2+f) of the classic fdlibm scheme.
 EPI_HD double s_log(double x)
@@ -141,7 +174,7 @@ EPI_HD float s_logf(float x)
     float m = u2f((ix & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
     float f = m - 1.0f;
-    float s = f / (2.0f + f);
+    float s = div_rn(f, 2.0f + f);
     float z = s * s;
     float w = z * z;
     float t1 = w * __builtin_fmaf(w, Lg4, Lg2);
@@ -158,7 +191,7 @@ EPI_HD float s_logf(float x)
 EPI_HD void box_muller(uint32_t w0, uint32_t w1, float& z0, float& z1)
 {
     float u1 = __builtin_fmaf((float)w0, 0x1p-32f, 0x1p-33f);   // (0, 1]
-    float r = __builtin_sqrtf(-2.0f * s_logf(u1));
+    float r = sqrt_rn(-2.0f * s_logf(u1));
     uint32_t quad = w1 >> 30;
     int32_t ti = (int32_t)(w1 & 0x3fffffffu) - (1 << 29);
     float y = ((float)ti + 0.5f) * 0x1p-30f;                    // [-1/2, 1/2]
@@ -339,11 +372,11 @@ EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, double lpq, const LfTable& l
     BtrsConsts C;
     C.nd = (double)n; C.pp = pp; C.lpq = lpq; C.lf = lf;
     // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
-    const double spq = (double)__builtin_sqrtf((float)(C.nd * pp * (1.0 - pp)));
+    const double spq = (double)sqrt_rn((float)(C.nd * pp * (1.0 - pp)));
     C.b = 1.15 + 2.53 * spq;
     C.a = -0.0873 + 0.0248 * C.b + 0.01 * pp;
     C.c = C.nd * pp + 0.5;
-    const double ib = (double)(1.0f / (float)C.b);
+    const double ib = (double)div_rn(1.0f, (float)C.b);
     C.vr = 0.92 - 4.2 * ib;
     C.alpha = (2.83 + 5.1 * ib) * spq;
     C.m = __builtin_floor((C.nd + 1.0) * pp);

@@ -291,6 +291,12 @@ int epi_pf_collect(epi_ctx *ctx, epi_belief *b, double *loglik, double *ess, uin
  * way.  enable = 0 forces the binary64 expression everywhere (testing aid,
  * process-wide). */
 int epi_debug_screen(int enable);
+/* The samplers take binary32 square roots and quotients whose operands are known to lie between 2^-30 and
+ * 2^32; on the device they use the hardware estimate plus the rounding correction, without the scaling and
+ * special-case steps of the general expansion.  This self-check evaluates both forms on every binary32 value in
+ * [first, last] (mode 0: sqrt(x); 1: 1/x; 2: f/(2+f) with f = x-1, the quotient inside the binary32 logarithm)
+ * and returns the number of values where the bits differ (must be 0).  No counterpart in the reference. */
+int epi_debug_f32_forms(epi_ctx *ctx, int mode, float first, float last, uint64_t *mismatches);
 /* Two implementations of the Philox-driven step kernel give identical results: the cooperative one
  * hands rejected sampler attempts to idle threads of the workgroup, the other loops per thread.
  * cooperative = 1 (default) picks by state width (cooperative up to H = 15, where its LDS footprint still

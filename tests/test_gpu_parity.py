@@ -431,6 +431,21 @@ def test_step_implementations_and_screens_agree(delay):
         check(lib.epi_debug_screen(1))
 
 
+def test_short_binary32_sqrt_and_quotient_are_correctly_rounded():
+    """The device forms of the binary32 square root and quotient used by the samplers against
+    the compiler's general expansions (what the host oracle's sqrtf and "/" compute), on EVERY
+    binary32 value of the operand ranges: sqrt over [2^-30, 2^32), 1/x over [1, 2^20), and the
+    quotient of the binary32 logarithm over its reduced argument range."""
+    ctx = em.interface.context_for(em.make_pomdp(LOD=5))
+    bad = C.c_uint64(1)
+    for mode, lo, hi in ((0, 2.0 ** -30, np.nextafter(np.float32(2.0 ** 32), np.float32(0))),
+                         (1, 1.0, np.nextafter(np.float32(2.0 ** 20), np.float32(0))),
+                         (2, 0.70710677, 1.4142137)):
+        check(ctx.lib.epi_debug_f32_forms(ctx.handle, mode, float(lo), float(hi), C.byref(bad)))
+        assert bad.value == 0, (mode, bad.value)
+    assert ctx.lib.epi_debug_f32_forms(ctx.handle, 3, 1.0, 2.0, C.byref(bad)) == -1        # EPI_EINVAL
+
+
 def test_wide_state_retry_queue_overflow_bit_exact():
     """H = 56 infection ages: 112 binomial draws per particle, so a workgroup's rejected first
     attempts exceed the retry queue and the in-thread completion path runs; still bit-exact."""
