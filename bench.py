@@ -172,6 +172,12 @@ def main():
                     help="after the timed region, run one gather dispatch of known traffic (PMC calibration)")
     args = ap.parse_args()
 
+    # libraries underneath (RCCL prints a version banner at start-up) write to stdout too: send everything to stderr
+    # while the benchmark runs, so that stdout carries the JSON line and nothing else
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = 0
     if args.gpus > 1 or args.sharded:
         pomdp, n, dt, kms, diag, rank = run_sharded(args)
@@ -207,7 +213,9 @@ def main():
     if args.gpus == 1 and not args.no_cpu:
         out["cpu_baseline_single_thread"] = cpu_baseline(pomdp, seconds_target=4.0, threads=1, n=100_000)
         out["cpu_baseline"] = cpu_baseline(pomdp)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
