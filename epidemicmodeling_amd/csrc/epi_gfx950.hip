@@ -273,7 +273,14 @@ __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A
 //   F  infection sum in bin order, new infections, outputs
 // LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues.
 // ---------------------------------------------------------------------------
-constexpr unsigned int QCAP = 2048;
+#ifndef EPI_COOP_TPB
+#define EPI_COOP_TPB 256
+#endif
+#ifndef EPI_COOP_QCAP
+#define EPI_COOP_QCAP 2048
+#endif
+constexpr int CTPB = EPI_COOP_TPB;               // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
+constexpr unsigned int QCAP = EPI_COOP_QCAP;
 
 // push `entry` for every lane that wants to (one LDS atomic per wave); false = queue full
 __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn)
@@ -305,7 +312,7 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
                            // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 #endif
 template <bool WEIGH>
-__global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
+__global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
     // Arguments needed only at the end of the kernel are re-read from the kernel-argument segment there (scalar
@@ -314,16 +321,16 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
     const KernArgs Ak = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = P.H, D = P.D;
-    int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][TPB]: (I_i, tested_i) -> (sympt_i, pos_i)
+    int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][CTPB]: (I_i, tested_i) -> (sympt_i, pos_i)
     int* slot_words = reinterpret_cast<int*>(smem);
-    double* gslots = reinterpret_cast<double*>(smem);                              // [H][TPB]: gamma term of the bin's survivors
-    unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * TPB * 8);
+    double* gslots = reinterpret_cast<double*>(smem);                              // [H][CTPB]: gamma term of the bin's survivors
+    unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * CTPB * 8);
     unsigned short* q1 = q0 + QCAP;
     unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP);                 // qn[0], qn[1]
-    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 2);     // [TPB/64]
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 2);     // [CTPB/64]
 
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * TPB;
+    const int64_t base = (int64_t)blockIdx.x * CTPB;
     const int64_t m = base + tid;
     const bool active = m < A.n;
     const int64_t src = active ? (A.anc ? (int64_t)A.anc[m] : m) : 0;
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
             const double ntf = __builtin_floor((double)(Ii - already) * a);        // simulate.jl:78
             const int32_t nt = (int32_t)ntf;
             if (nt < 0) flags |= EPI_F_NEG_NT;
-            slots[i * TPB + tid] = make_int2(Ii, nt);
+            slots[i * CTPB + tid] = make_int2(Ii, nt);
             suminf_pre += Ii;
             if constexpr (WEIGH) {
                 const double pi = P.p[i];
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
 #pragma unroll 1
     for (int i = 0; i < H; i++) {
         if (active) {
-            int2 nn = slots[i * TPB + tid];
+            int2 nn = slots[i * CTPB + tid];
             uint32_t w[4];
             rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
             unsigned int failbits = 0u;
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 if (j) nn.y = res; else nn.x = res;
                 failbits |= (unsigned int)fail << j;
             }
-            slots[i * TPB + tid] = nn;
+            slots[i * CTPB + tid] = nn;
             if (i < 32) fm0 |= (unsigned long long)failbits << (2 * i);
             else fm1 |= (unsigned long long)failbits << (2 * (i - 32));
         }
@@ -429,9 +436,9 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 const int i = (bit >> 1) + 32 * half, j = bit & 1;
                 if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14));
                 else {                                                              // queue full: finish here
-                    const int32_t n = slot_words[(i * TPB + tid) * 2 + j];
+                    const int32_t n = slot_words[(i * CTPB + tid) * 2 + j];
                     const int32_t k = btrs_finish(btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
-                    slot_words[(i * TPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
+                    slot_words[(i * CTPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
                 }
                 pos++;
             }
@@ -452,10 +459,10 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
             const unsigned short* q = cur ? q1 : q0;
             unsigned short* qnext = cur ? q0 : q1;
 #pragma unroll 1
-            for (unsigned int e = tid; e < cnt; e += TPB) {
+            for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
-                const int32_t n = slot_words[(i * TPB + t) * 2 + j];
+                const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
                 const bool flip = Dp->flip[j][i] != 0;                             // a queued draw is a rejection draw
                 const BtrsConsts C = btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 const bool fail = k < 0;
                 const bool pushed = q_push(fail, entry, qnext, &qn[cur ^ 1]);
                 if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);
-                if (k >= 0) slot_words[(i * TPB + t) * 2 + j] = flip ? n - k : k;
+                if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
             }
             cur ^= 1;
         }
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         const int i = it == 0 ? H - 1 : it - 1;
         bool gfail = false;
         if (active) {
-            const int2 sp = slots[i * TPB + tid];
+            const int2 sp = slots[i * CTPB + tid];
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
             if (it + 1 < H) I_next = in[(int64_t)(2 + it) * is + src];             // bin of iteration it+1
@@ -515,18 +522,18 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 box_muller(w[0], w[1], z0, z_odd);
                 zf = z0; wu = w[2]; w_odd = w[3];
             }
-            if (gamma_is_zero(shape)) gslots[i * TPB + tid] = 0.0;
+            if (gamma_is_zero(shape)) gslots[i * CTPB + tid] = 0.0;
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
                 double v;
-                if (gamma_attempt(G, zf, wu, v)) gslots[i * TPB + tid] = gamma_finish(G, v, P.theta[it], g, (uint32_t)it);
-                else { slots[i * TPB + tid] = make_int2(Ii, 0); gfail = true; }
+                if (gamma_attempt(G, zf, wu, v)) gslots[i * CTPB + tid] = gamma_finish(G, v, P.theta[it], g, (uint32_t)it);
+                else { slots[i * CTPB + tid] = make_int2(Ii, 0); gfail = true; }
             }
         }
         const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[0]);
         if (gfail && !gpushed) {
-            const int32_t Ii = slots[i * TPB + tid].x;
-            gslots[i * TPB + tid] = gamma_finish_from(gamma_consts(P.k[it] * (double)Ii, screen), P.theta[it], g, (uint32_t)it, 1u);
+            const int32_t Ii = slots[i * CTPB + tid].x;
+            gslots[i * CTPB + tid] = gamma_finish_from(gamma_consts(P.k[it] * (double)Ii, screen), P.theta[it], g, (uint32_t)it, 1u);
         }
     }
 
@@ -544,11 +551,11 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
             const unsigned short* q = cur ? q1 : q0;
             unsigned short* qnext = cur ? q0 : q1;
 #pragma unroll 1
-            for (unsigned int e = tid; e < cnt; e += TPB) {
+            for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
                 const int t = entry & 255, it = entry >> 8;
                 const int i = it == 0 ? H - 1 : it - 1;
-                const int32_t Ii = slots[i * TPB + t].x;
+                const int32_t Ii = slots[i * CTPB + t].x;
                 const GammaConsts G = gamma_consts(P.k[it] * (double)Ii, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 float zf; uint32_t wu;
@@ -556,8 +563,8 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
                 double v;
                 const bool ok = gamma_attempt(G, zf, wu, v);
                 const bool pushed = q_push(!ok, entry, qnext, &qn[cur ^ 1]);
-                if (ok) gslots[i * TPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
-                else if (!pushed) gslots[i * TPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
+                if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
+                else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
             }
             cur ^= 1;
         }
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
     if (active) {
         double infsum = 0.0;
 #pragma unroll 1
-        for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * TPB + tid];   // simulate.jl:38-41
+        for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * CTPB + tid];   // simulate.jl:38-41
         const int64_t denom = P.N - (int64_t)R;
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
@@ -600,13 +607,13 @@ __global__ __launch_bounds__(TPB, EPI_COOP_WAVES) void k_step_coop(const StepArg
         __syncthreads();
         if (tid == 0) {
             unsigned long long c = s_max[0];
-            for (int w = 1; w < TPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
+            for (int w = 1; w < CTPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
             atomicMax(&Ak->scal->lwmax_bits, c);
         }
     }
 }
 
-static size_t coop_lds_bytes(int H) { return (size_t)H * TPB * 8 + 2 * QCAP * sizeof(unsigned short) + 2 * sizeof(unsigned int) + (TPB / 64) * sizeof(unsigned long long); }
+static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 2 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long); }
 
 static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by state width, 2 cooperative
 
@@ -614,7 +621,6 @@ static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by stat
 template <bool WEIGH>
 static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
 {
-    const dim3 grid((unsigned)ceil_div(A.n, TPB)), blk(TPB);
     // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 15 four workgroups share a CU and it is
     // the faster one (2.2 vs 1.6e9 particle-steps/s at H = 14); wider states leave it one or two workgroups per CU
     // and the per-thread kernel wins (H = 28: 0.72 vs 0.88e9, H = 56: 0.25 vs 0.54e9).
@@ -624,9 +630,9 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        k_step_coop<WEIGH><<<grid, blk, lds, c->stream>>>(A, c->d_params);
+        k_step_coop<WEIGH><<<dim3((unsigned)ceil_div(A.n, CTPB)), dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
-        k_step<WEIGH, MODE_PHILOX><<<grid, blk, 0, c->stream>>>(A, c->d_params);
+        k_step<WEIGH, MODE_PHILOX><<<dim3((unsigned)ceil_div(A.n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
     }
     return hipGetLastError();
 }
