@@ -730,6 +730,38 @@ def test_random_parameter_sets_bit_exact(seed):
     _eq(b.download(), exp)
 
 
+def test_maximum_state_shape_bit_exact():
+    """EPI_MAX_H = 64 infection ages with EPI_MAX_D = 7 days of test delay (507 state rows), population close
+    to the int32 limit: plain steps, filter updates and the mean against the oracle."""
+    H, D, N = 64, 7, 2_000_000_000
+    rng = np.random.default_rng(77)
+    p = np.clip(rng.random(H) * 1.2 - 0.1, 0.0, 1.0)
+    shapes = 10.0 ** rng.uniform(-4, 0.5, H)
+    pomdp = em.make_pomdp(horizon=H, test_delay=D, N=N, pos_test_probs=list(p), Infdistributions=list(zip(shapes, [0.05] * H)))
+    assert em.interface.context_for(pomdp).lib.epi_state_rows(H, D) == 2 + H + D * (H - 1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 700
+    st = random_states(pomdp, n, rng, scale=N // (3 * H))
+    b = _belief(pomdp, st)
+    exp = st
+    for step in range(3):                                             # fills the test pipeline rows
+        o, r, fl = em.step_batch(b, 0.4, a_prev=0.4 if step else 0.0, seed=11, step=step)
+        exp, eo, er, _, efl = orc.step_batch(exp, 0.4, 0.4 if step else 0.0, seed=11, step=step)
+        assert (o == eo).all() and fl == efl and (r.view(np.uint64) == er.view(np.uint64)).all()
+    _eq(b.download(), exp)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    _, mu, _ = orc.log_weights(exp, 0.4, 0)
+    obs = int(np.median(mu))
+    em.update(upd, b, em.Action(0.4), obs)
+    exp, info = orc.pf_update(exp, 0.4, obs, SEED, 0)
+    assert upd.last_flags == info["flags"]
+    _eq(b.download(), exp)
+    m = em.mean(b)
+    eS, eI, eR, eT, bad = orc.mean(exp)
+    assert not bad and m.S == eS and m.R == eR and (m.I == eI).all() and (m.Tests == eT.T).all()
+    b.close()
+
+
 # ---------------------------------------------------------------------------
 # the device samplers against the closed-form distributions, at a sample size the CPU suite does not reach
 # ---------------------------------------------------------------------------
