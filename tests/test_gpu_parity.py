@@ -205,6 +205,26 @@ def test_pf_closed_loop_bit_exact(delay):
         assert (m.S, m.R) == (eS, eR) and (m.I == eI).all() and (m.Tests == eT.T).all()
 
 
+def test_pf_million_particles_bit_exact():
+    """Three successive updates of 10^6 particles against the oracle: every posterior particle, ancestor
+    concentration included (the second and third updates resample a belief that already holds duplicates)."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n, a = 1_000_000, 0.2
+    st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
+    b = em.initialbelief(pomdp, n, seed=SEED)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    for day in range(3):
+        _, mu, _ = orc.log_weights(st, a, 0)
+        o = int(np.percentile(mu, 40 + 10 * day))
+        em.update(upd, b, em.Action(a), o)
+        st, info = orc.pf_update(st, a, o, SEED, day)
+        assert upd.last_flags == info["flags"] == 0
+        assert 1_000 < info["ess"] < n and abs(upd.last_ess - info["ess"]) <= 1e-9 * info["ess"]
+    _eq(b.download(), st)
+    b.close()
+
+
 def test_pf_degenerate_weights():
     pomdp = em.make_pomdp(LOD=5)
     orc = pyoracle.Oracle(pomdp.to_c())
