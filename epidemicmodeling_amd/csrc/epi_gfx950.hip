@@ -338,9 +338,16 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     const double a = active ? (A.a_dev ? A.a_dev[arow * A.a_row_stride + A.a_col] : A.a) : 0.0;
     const Rng g = rng_make(A.seed, A.slot0 + (uint64_t)m, A.step);
     const bool screen = A.screen != 0;
-    const int32_t* __restrict__ in = A.in;
-    int32_t* __restrict__ out = A.out;
-    const int64_t is = A.in_stride, os = A.out_stride;
+    // The row strides and base pointers arrive in one wide scalar load; copied into register pairs of their own,
+    // a reload after a scalar-register spill restores two registers instead of the whole eight-register tuple.
+    uint64_t in_u, out_u, is_u, os_u;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(in_u) : "s"((uint64_t)A.in));
+    asm volatile("s_mov_b64 %0, %1" : "=s"(out_u) : "s"((uint64_t)A.out));
+    asm volatile("s_mov_b64 %0, %1" : "=s"(is_u) : "s"((uint64_t)A.in_stride));
+    asm volatile("s_mov_b64 %0, %1" : "=s"(os_u) : "s"((uint64_t)A.out_stride));
+    const int32_t* __restrict__ in = (const int32_t*)in_u;
+    int32_t* __restrict__ out = (int32_t*)out_u;
+    const int64_t is = (int64_t)is_u, os = (int64_t)os_u;
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; }
     unsigned int flags = 0;
     int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
