@@ -51,6 +51,17 @@ EPI_HD Rng rng_make(uint64_t seed, uint64_t slot, uint32_t step)
     return g;
 }
 
+// a ^ b ^ c.  gfx950 has a three-operand bitwise instruction (truth table 0x96 = parity), which the compiler does
+// not select for a chain of two exclusive-ors by itself.
+EPI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EPI_NO_BITOP3)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).
 EPI_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                           uint32_t k0, uint32_t k1, uint32_t (&w)[4])
@@ -59,9 +70,11 @@ EPI_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     for (int r = 0; r < 10; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        // round 0 mixes wave-uniform words (step, stream tag, key): plain operators let the compiler keep those
+        // parts in scalar registers
+        uint32_t n0 = r == 0 ? (uint32_t)(p1 >> 32) ^ c1 ^ k0 : xor3((uint32_t)(p1 >> 32), c1, k0);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = r == 0 ? (uint32_t)(p0 >> 32) ^ c3 ^ k1 : xor3((uint32_t)(p0 >> 32), c3, k1);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -75,7 +88,23 @@ EPI_HD void rng_block(const Rng& g, uint32_t kind, uint32_t bin, uint32_t blk, u
 }
 
 // uniform in (0,1): (w + 1/2) 2^-32, exact in binary64
+#ifdef EPI_U01_BITS
+EPI_HD double u01_plus1(uint32_t w)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t hi = __builtin_amdgcn_alignbit(0x3FFu, w, 12);       // 0x3FF00000 | w >> 12
+    const uint32_t lo = (w << 20) | 0x80000u;
+    return u2d(((uint64_t)hi << 32) | lo);
+#else
+    return u2d(0x3FF0000000080000ULL | ((uint64_t)w << 20));
+#endif
+}
+EPI_HD double u01(uint32_t w) { return u01_plus1(w) - 1.0; }
+EPI_HD double u01_centred(uint32_t w) { return u01_plus1(w) - 1.5; }
+#else
 EPI_HD double u01(uint32_t w) { return ((double)w + 0.5) * 0x1p-32; }
+EPI_HD double u01_centred(uint32_t w) { return u01(w) - 0.5; }
+#endif
 
 // ---- elementary functions ---------------------------------------------------
 
@@ -439,7 +468,7 @@ EPI_HD double btrs_k(const BtrsConsts& C, double u, double us)
 // one attempt: returns the accepted k (>= 0) or -1
 EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
 {
-    const double u = u01(wa) - 0.5;
+    const double u = u01_centred(wa);
     const double v = u01(wb);
     const double us = 0.5 - __builtin_fabs(u);
     const double kd = btrs_k(C, u, us);

@@ -21,7 +21,7 @@ src/POMDPsInterface.jl:56, src/MPC.jl:393):
   6. slots of that range owned by another rank: the resampled particles are
      packed and sent directly to the owner (pairwise send/recv, no ring);
      slots owned locally only get an ancestor index (the gather is folded into
-     the next step kernel).
+     the next step kernel), selected while the exchange is in flight.
 """
 from __future__ import annotations
 
@@ -238,14 +238,16 @@ class ShardedFilter:
                 buf = sh.recv_buffer(r1 - r0)
                 recvs.append((r0, r1, buf.cpu() if self.stage else buf))
                 ops.append(dist.P2POp(dist.irecv, recvs[-1][2], h))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for r0, r1, buf in recvs:
-            sh.import_(r0, r1, buf.to(self.comm_device) if self.stage else buf)
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        # the ancestors of the slots that stay on this rank are selected while the exchange is in flight (RCCL works
+        # on a stream of its own; the import below is ordered after it by the wait)
         s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
         if s1 > s0:
             sh.select_local(g, w_shard, seed, step, s0, s1)
+        for req in reqs:
+            req.wait()
+        for r0, r1, buf in recvs:
+            sh.import_(r0, r1, buf.to(self.comm_device) if self.stage else buf)
         if device_handover:
             sh.finish(want_flags=False)
         else:

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_div(const double* x, double* out, int64
 // issue rate of single instructions: 8 independent dependency chains per lane, OPS_REP rounds
 constexpr int OPS_REP = 256;
 enum { OP_FMA64, OP_FMA32, OP_PKFMA32, OP_MAD64, OP_MULLO, OP_MULHI, OP_XOR, OP_RCP32, OP_SQRT32, OP_LOG32, OP_RCP64, OP_CVT_F64_U32,
-       OP_CVT_F32_F64, OP_FLOOR64, OP_MUL64, OP_ADD64, OP_LDEXP64, OP_CNDMASK };
+       OP_CVT_F32_F64, OP_FLOOR64, OP_MUL64, OP_ADD64, OP_LDEXP64, OP_CNDMASK, OP_BITOP3, OP_XOR2 };
 template <int OP>
 __global__ __launch_bounds__(256) void k_ops(const double* x, double* out, int64_t n)
 {
@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void k_ops(const double* x, double* out, int64
             else if constexpr (OP == OP_FLOOR64) d[c] = __builtin_floor(d[c]) + 0.5;
             else if constexpr (OP == OP_LDEXP64) d[c] = __builtin_ldexp(d[c], (int)(u[c] & 1u));
             else if constexpr (OP == OP_CNDMASK) u[c] = (u[c] & 1u) ? u[c] + 7u : u[c] >> 1;
+            else if constexpr (OP == OP_BITOP3) u[c] = __builtin_amdgcn_bitop3_b32(u[c], u[(c + 3) & 7], (uint32_t)r, 0x96);
+            else if constexpr (OP == OP_XOR2) { uint32_t t = u[c] ^ u[(c + 3) & 7]; asm volatile("" : "+v"(t)); u[c] = t ^ (uint32_t)r; }
         }
     }
     double acc = 0;
@@ -214,7 +216,7 @@ int main()
 #define OPT(OP, per) rep2(#OP, timeit([&] { k_ops<OP><<<g2, blk>>>((double*)in, (double*)out, m); }), per)
         OPT(OP_FMA64, 1); OPT(OP_MUL64, 1); OPT(OP_ADD64, 1); OPT(OP_FMA32, 1); OPT(OP_PKFMA32, 1); OPT(OP_MAD64, 1); OPT(OP_MULLO, 2); OPT(OP_MULHI, 2);
         OPT(OP_XOR, 3); OPT(OP_RCP32, 2); OPT(OP_SQRT32, 2); OPT(OP_LOG32, 2); OPT(OP_RCP64, 2); OPT(OP_CVT_F64_U32, 3); OPT(OP_CVT_F32_F64, 3);
-        OPT(OP_FLOOR64, 2); OPT(OP_LDEXP64, 2); OPT(OP_CNDMASK, 4);
+        OPT(OP_FLOOR64, 2); OPT(OP_LDEXP64, 2); OPT(OP_CNDMASK, 4); OPT(OP_BITOP3, 1); OPT(OP_XOR2, 2);
     }
     {
         unsigned int* st; unsigned long long* cnt;
