@@ -4,7 +4,7 @@ import numpy as np
 import epidemicmodeling_amd as em
 from epidemicmodeling_amd import _lib
 lib = _lib.load()
-for H in (14, 28, 56):
+for H in (14, 16, 21, 28, 56, 64):
     pomdp = em.make_pomdp(LOD=5, horizon=H)
     n, T = 4_000_000, 10
     for impl in (1, 0):
@@ -14,6 +14,6 @@ for H in (14, 28, 56):
         t0 = time.perf_counter()
         em.rollout_batch(b, T, 0.2, seed=2, want_hist=False, want_rew=False)
         dt = time.perf_counter() - t0
-        print(f"H={H} impl={'coop' if impl else 'per-thread'}: {n*T/dt:.3e} particle-steps/s")
+        print(f"H={H} impl={('per-thread', 'default')[impl]}: {n*T/dt:.3e} particle-steps/s")
         b.close()
 lib.epi_debug_step_impl(1)
