@@ -26,6 +26,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
+SIMD_CLOCK_HZ = 2.4e9           # nominal engine clock
+N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
+# issue cycles of one wave64 vector instruction on its SIMD with the SIMD's other waves issuing too, by counter class
+# (tools/ubench.hip: binary64 add / mul / fma 5.2-5.6, conversions 3-4, binary32 fma 4.7, 64-bit integer multiply-add
+# 7.2, 32-bit integer 2.5-2.8, binary32 transcendentals ~7, binary64 reciprocal ~16, compares / selects / moves ~3)
+VALU_ISSUE_CYCLES = {"valu_add_f64": 5.2, "valu_mul_f64": 5.6, "valu_fma_f64": 5.3, "valu_trans_f64": 16.0, "valu_cvt": 3.5,
+                     "valu_fma_f32": 4.7, "valu_int64": 7.2, "valu_int32": 2.7, "valu_trans_f32": 7.0, "other": 3.0}
 SEED = 0x5EED
 ACTION = 0.2
 
@@ -197,6 +204,23 @@ def main():
             traffic = json.load(open(tpath))["k_step_hbm_bytes_per_particle"] * n_launch
         except Exception:
             traffic = None
+    # The step kernel is bound by vector-instruction issue, not by HBM.  Next to the HBM roofline: the SIMD cycles one
+    # wavefront's step takes (live kernel time at the nominal 2.4 GHz, 1024 SIMDs) against the issue cycles of the
+    # vector instructions it executes (per-class counts from the SQ counter pass of tools/pmc_step.sh, committed as
+    # profiles/pmc_valu.json, times the issue cost of each class measured by tools/ubench.hip on this chip).
+    issue = None
+    vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+    if kms > 0 and os.path.exists(vpath) and H == 14 and D == 0:
+        try:
+            mix = json.load(open(vpath))["insts_per_wave_step"]
+            cyc = kms * 1e-3 * SIMD_CLOCK_HZ * N_SIMD / (n_launch / 64.0)
+            classed = sum(mix[k] for k in VALU_ISSUE_CYCLES if k != "other")
+            need = sum(mix[k] * c for k, c in VALU_ISSUE_CYCLES.items() if k != "other")
+            need += (mix["valu"] - classed) * VALU_ISSUE_CYCLES["other"]
+            issue = {"bound": "valu-issue", "valu_insts_per_wave_step": mix["valu"], "simd_cycles_per_wave_step": cyc,
+                     "issue_cycles_of_the_mix": need, "frac": need / cyc}
+        except Exception:
+            issue = None
     out = {
         "metric": "particle-steps/sec (whole node) at 10^8 particles; % of HBM roofline",
         "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -208,6 +232,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                      "kernel": "k_step_coop<true>", "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
+        "issue": issue,
         "diagnostics": diag,
     }
     if args.gpus == 1 and not args.no_cpu:
