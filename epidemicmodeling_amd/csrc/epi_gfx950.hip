@@ -89,6 +89,11 @@ struct epi_ctx {
     DevParams* d_params = nullptr;      // parameters + derived per-bin constants, as the kernels read them
     double* d_lf = nullptr;             // lfact(k), k < LF_TABLE_N
     long long* d_sums = nullptr;        // 2 + H + (D+1) H column sums
+    // Small buffers that live as long as the context, so that scalar read-backs do not go through pageable memory and
+    // calls on small populations (the true state of a closed loop is a population of one) do not allocate: a context
+    // runs one call at a time, and every call that uses them has waited for the stream before it returns.
+    unsigned char* h_pin = nullptr;     // PIN_BYTES of page-locked host memory
+    unsigned char* d_small = nullptr;   // SMALL_BYTES of device scratch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     bool timing = false;                // record an event pair around every fused step kernel of an update
@@ -130,6 +135,9 @@ static const int TPB = 256;            // threads per workgroup
 static const int LF_TABLE_N = 1 << 20; // tabulated log factorials (8 MB per context); larger arguments are computed
 static const int SCAN_ITEMS = 8;       // fixed-point weights per thread in the scan kernels
 static const int SCAN_TILE = TPB * SCAN_ITEMS;
+
+static const size_t PIN_BYTES = 128 << 10;
+static const size_t SMALL_BYTES = 128 << 10;
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -1249,6 +1257,25 @@ struct DevBuf {          // device scratch freed on scope exit
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
+struct Arena {           // device scratch of one call: carved from the context's small buffer while it lasts, else allocated
+    epi_ctx* c;
+    size_t used = 0;
+    std::vector<void*> owned;
+    explicit Arena(epi_ctx* ctx) : c(ctx) {}
+    Arena(const Arena&) = delete;
+    Arena& operator=(const Arena&) = delete;
+    ~Arena() { for (void* p : owned) (void)hipFree(p); }
+    void* get(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (used + bytes <= SMALL_BYTES) { void* p = c->d_small + used; used += bytes; return p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        owned.push_back(p);
+        return p;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -1265,18 +1292,27 @@ int epi_ctx_create(int device, epi_ctx** out)
     HIPCHECK(hipSetDevice(device));
     epi_ctx* c = new epi_ctx();
     c->device = device;
-    HIPCHECK(hipStreamCreate(&c->own_stream));
-    c->stream = c->own_stream;
-    HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
-    HIPCHECK(hipMemset(c->d_scal, 0, 256));
-    HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
-    HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
-    k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
-    HIPCHECK(hipEventCreate(&c->ev0));
-    HIPCHECK(hipEventCreate(&c->ev1));
+    const int rc = [c]() -> int {
+        HIPCHECK(hipStreamCreate(&c->own_stream));
+        c->stream = c->own_stream;
+        HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
+        HIPCHECK(hipMemset(c->d_scal, 0, 256));
+        HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
+        HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
+        k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
+        HIPCHECK(hipHostMalloc((void**)&c->h_pin, PIN_BYTES, hipHostMallocDefault));
+        HIPCHECK(hipMalloc((void**)&c->d_small, SMALL_BYTES));
+        HIPCHECK(hipEventCreate(&c->ev0));
+        HIPCHECK(hipEventCreate(&c->ev1));
+        return EPI_OK;
+    }();
+    if (rc != EPI_OK) {                 // release what was created before the failure (the message is already set)
+        (void)epi_ctx_destroy(c);
+        return rc;
+    }
     *out = c;
     return EPI_OK;
 }
@@ -1292,6 +1328,8 @@ int epi_ctx_destroy(epi_ctx* c)
     if (c->d_sums) (void)hipFree(c->d_sums);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_lf) (void)hipFree(c->d_lf);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return EPI_OK;
@@ -1454,8 +1492,8 @@ int epi_belief_upload(epi_belief* b, const int64_t* S, const int64_t* I, const i
         }
     }
     HIPCHECK(hipStreamSynchronize(c->stream));
-    for (int r = 0; r < b->rows; r++)
-        HIPCHECK(hipMemcpy(b->buf[b->cur] + (size_t)r * (size_t)b->stride, h.data() + (size_t)r * (size_t)n, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy2D(b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, h.data(), sizeof(int32_t) * (size_t)n, sizeof(int32_t) * (size_t)n, (size_t)b->rows,
+                         hipMemcpyHostToDevice));
     b->has_anc = false;
     b->phase = PH_IDLE;
     return EPI_OK;
@@ -1473,9 +1511,19 @@ int epi_belief_download(epi_belief* b, int64_t* S, int64_t* I, int64_t* R, int64
     rc = materialize(b);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));
-    std::vector<int32_t> h((size_t)b->rows * (size_t)n);
-    for (int r = 0; r < b->rows; r++)
-        HIPCHECK(hipMemcpy(h.data() + (size_t)r * (size_t)n, b->buf[b->cur] + (size_t)r * (size_t)b->stride, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    // all rows in one strided copy; a small population comes back through the page-locked buffer
+    const size_t row_bytes = sizeof(int32_t) * (size_t)n;
+    std::vector<int32_t> hv;
+    const int32_t* h;
+    if (row_bytes * (size_t)b->rows <= PIN_BYTES) {
+        HIPCHECK(hipMemcpy2DAsync(c->h_pin, row_bytes, b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, row_bytes, (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        h = reinterpret_cast<const int32_t*>(c->h_pin);
+    } else {
+        hv.resize((size_t)b->rows * (size_t)n);
+        HIPCHECK(hipMemcpy2D(hv.data(), row_bytes, b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, row_bytes, (size_t)b->rows, hipMemcpyDeviceToHost));
+        h = hv.data();
+    }
     for (int64_t p = 0; p < n; p++) {
         if (S) S[p] = h[(size_t)p];
         if (R) R[p] = h[(size_t)n + (size_t)p];
@@ -1542,11 +1590,20 @@ int epi_belief_init_simplex(epi_belief* b, uint64_t seed)
 // ---- the step ------------------------------------------------------------------
 
 
+// the context's scalars, read back through the page-locked staging buffer; waits for the stream
+static int read_scalars(epi_ctx* c, DevScalars* h)
+{
+    static_assert(sizeof(DevScalars) <= 256, "DevScalars outgrew its allocation");
+    HIPCHECK(hipMemcpyAsync(c->h_pin, c->d_scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    memcpy(h, c->h_pin, sizeof(DevScalars));
+    return EPI_OK;
+}
+
 static int fetch_flags(epi_ctx* c, uint32_t* flags, bool reset)
 {
     DevScalars h;
-    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (int rs = read_scalars(c, &h)) return rs;
     if (flags) *flags = h.flags;
     if (reset) HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
     return EPI_OK;
@@ -1563,7 +1620,8 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
     if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_batch: a phased update is in progress");
     HIPCHECK(hipSetDevice(c->device));
     const int64_t n = b->n;
-    DevBuf da, dap, dob, dr, dni;
+    Arena scratch(c);
+    const char* nomem = "epi_step_batch: hipMalloc failed";
     StepArgs A;
     memset(&A, 0, sizeof A);
     A.screen = g_screen;
@@ -1571,28 +1629,50 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
     if (a_per_particle) {
-        if (da.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed");
-        HIPCHECK(hipMemcpyAsync(da.p, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        A.a_dev = da.as<double>();
+        double* da = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n));
+        if (!da) return fail(EPI_ENOMEM, nomem);
+        HIPCHECK(hipMemcpyAsync(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        A.a_dev = da;
     }
     A.a_prev = a_prev ? a_prev[0] : 0.0;
     if (a_prev && a_prev_per_particle) {
-        if (dap.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed");
-        HIPCHECK(hipMemcpyAsync(dap.p, a_prev, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        A.a_prev_dev = dap.as<double>();
+        double* dap = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n));
+        if (!dap) return fail(EPI_ENOMEM, nomem);
+        HIPCHECK(hipMemcpyAsync(dap, a_prev, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        A.a_prev_dev = dap;
     }
     A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
-    if (o_out) { if (dob.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.o_out = dob.as<int32_t>(); }
-    if (r_out) { if (dr.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.r_out = dr.as<double>(); }
-    if (new_inf_out) { if (dni.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_batch: hipMalloc failed"); A.newinf_out = dni.as<int32_t>(); }
+    if (o_out && !(A.o_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
+    if (r_out && !(A.r_out = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
+    if (new_inf_out && !(A.newinf_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
     HIPCHECK(launch_step<false>(c, A));
-    std::vector<int32_t> h((size_t)n);
-    if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), dob.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
-    if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), dni.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
-    if (r_out) HIPCHECK(hipMemcpyAsync(r_out, dr.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    rc = fetch_flags(c, flags, true);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if ((size_t)n * 16 + 256 <= PIN_BYTES) {
+        // small population: outputs and scalars come back through the page-locked buffer with one wait
+        unsigned char* hp = c->h_pin;
+        int32_t* ho = reinterpret_cast<int32_t*>(hp + 256);
+        int32_t* hn = ho + n;
+        double* hr = reinterpret_cast<double*>(hp + 256 + 8 * (size_t)n);
+        HIPCHECK(hipMemcpyAsync(hp, c->d_scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
+        if (o_out) HIPCHECK(hipMemcpyAsync(ho, A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        if (new_inf_out) HIPCHECK(hipMemcpyAsync(hn, A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        if (r_out) HIPCHECK(hipMemcpyAsync(hr, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        if (flags) *flags = reinterpret_cast<const DevScalars*>(hp)->flags;
+        for (int64_t i = 0; i < n; i++) {
+            if (o_out) o_out[i] = ho[i];
+            if (new_inf_out) new_inf_out[i] = hn[i];
+            if (r_out) r_out[i] = hr[i];
+        }
+    } else {
+        std::vector<int32_t> h((size_t)n);
+        if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
+        if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
+        if (r_out) HIPCHECK(hipMemcpyAsync(r_out, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        rc = fetch_flags(c, flags, true);
+        if (rc) return rc;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+    }
     b->cur ^= 1; b->has_anc = false;
     return EPI_OK;
 }
@@ -2056,8 +2136,7 @@ int epi_pf_collect(epi_ctx* c, epi_belief* b, double* loglik, double* ess, uint3
     if (!c || !b) return fail(EPI_EINVAL, "epi_pf_collect: NULL argument");
     HIPCHECK(hipSetDevice(c->device));
     DevScalars h;
-    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (int rs = read_scalars(c, &h)) return rs;
     uint32_t f = h.flags;
     if (h.w_total == 0ULL) f |= EPI_F_ZERO_W;
     if (flags) *flags = f;
@@ -2169,8 +2248,7 @@ int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed
     rc = launch_predict(c, b, a, o, seed, step);
     if (rc) return rc;
     DevScalars h;
-    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (int rs = read_scalars(c, &h)) return rs;
     if (lwmax_local) *lwmax_local = h.lwmax_bits ? order_decode(h.lwmax_bits) : -INFINITY;
     b->phase = PH_PREDICTED;
     return EPI_OK;
@@ -2187,8 +2265,7 @@ int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_loc
     rc = launch_weigh(c, b);
     if (rc) return rc;
     DevScalars h;
-    HIPCHECK(hipMemcpyAsync(&h, c->d_scal, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    if (int rs = read_scalars(c, &h)) return rs;
     if (w_local) *w_local = h.w_local;
     if (sumsq_local) *sumsq_local = h.sumsq;
     if (flags_local) *flags_local = h.flags;
@@ -2355,8 +2432,8 @@ int epi_belief_sums(epi_ctx* c, epi_belief* b, int64_t* sums)
     if (gx > 1024) gx = 1024;
     k_sums<<<dim3((unsigned)gx, (unsigned)b->rows), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->d_sums);
     HIPCHECK(hipGetLastError());
-    std::vector<long long> h((size_t)b->rows);
-    HIPCHECK(hipMemcpyAsync(h.data(), c->d_sums, sizeof(long long) * (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
+    const long long* h = reinterpret_cast<const long long*>(c->h_pin);          // rows <= 2 + H + D (H - 1): a few KB
+    HIPCHECK(hipMemcpyAsync(c->h_pin, c->d_sums, sizeof(long long) * (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     sums[0] = h[0]; sums[1] = h[1];
     for (int i = 0; i < H; i++) sums[2 + i] = h[(size_t)(2 + i)];
@@ -2399,10 +2476,15 @@ int epi_belief_suminf_quantiles(epi_ctx* c, epi_belief* b, const double* q, int 
     for (int j = 0; j < nq; j++) if (!(q[j] >= 0.0 && q[j] <= 1.0)) return fail(EPI_EINVAL, "epi_belief_suminf_quantiles: q[%d] = %g", j, q[j]);
     HIPCHECK(hipSetDevice(c->device));
     const int64_t n = b->n;
-    DevBuf dv, dh;
-    if (dv.alloc(sizeof(int32_t) * (size_t)n) != hipSuccess || dh.alloc(sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS) != hipSuccess)
-        return fail(EPI_ENOMEM, "epi_belief_suminf_quantiles: hipMalloc failed");
-    k_suminf<<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->P.H, dv.as<int32_t>());
+    // scratch: the infected totals go where the log weights of an update live (free between updates, 8 n bytes);
+    // the histograms into the context's small buffers
+    static_assert(sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS <= SMALL_BYTES && sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS <= PIN_BYTES,
+                  "histograms outgrew the context's small buffers");
+    int32_t* const dv = reinterpret_cast<int32_t*>(b->lw);
+    unsigned long long* const dh = reinterpret_cast<unsigned long long*>(c->d_small);
+    unsigned long long* const h = reinterpret_cast<unsigned long long*>(c->h_pin);
+    const size_t hist_bytes = sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS;
+    k_suminf<<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->P.H, dv);
     // 1-based rank of each quantile: the smallest value with at least ceil(q n) values <= it (rank 1 for q = 0)
     int64_t rank[QSEL_MAX];
     for (int j = 0; j < nq; j++) {
@@ -2413,15 +2495,14 @@ int epi_belief_suminf_quantiles(epi_ctx* c, epi_belief* b, const double* q, int 
     memset(&P, 0, sizeof P);
     P.nq = nq;
     const int shifts[3] = {20, 9, 0}, bins[3] = {2048, 2048, 512};
-    std::vector<unsigned long long> h((size_t)QSEL_MAX * QSEL_BINS);
     int64_t gx = ceil_div(n, (int64_t)TPB * 16);
     gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
     for (int pass = 0; pass < 3; pass++) {
         P.shift = shifts[pass]; P.bins = bins[pass]; P.hi_shift = pass == 0 ? 32 : shifts[pass - 1];
-        HIPCHECK(hipMemsetAsync(dh.p, 0, sizeof(unsigned long long) * h.size(), c->stream));
-        k_qsel_hist<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(n, dv.as<int32_t>(), P, dh.as<unsigned long long>());
+        HIPCHECK(hipMemsetAsync(dh, 0, hist_bytes, c->stream));
+        k_qsel_hist<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(n, dv, P, dh);
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipMemcpyAsync(h.data(), dh.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipMemcpyAsync(h, dh, hist_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(hipStreamSynchronize(c->stream));
         for (int j = 0; j < nq; j++) {
             unsigned long long acc = 0;

@@ -227,13 +227,20 @@ def gen(pomdp: CovidPOMDP, s: State, a: Action, seed: int = _DEFAULT_SEED, step:
     sub-steps under one action; returns (sp, o of the LAST sub-step, summed r).
     Sub-step i uses stream step * test_period + i."""
     b = ParticleCollection.from_states(pomdp, [s], device)
+    o, rsum = _gen_in_place(pomdp, b, a, seed, step)
+    sp = b.particles[0]
+    b.close()
+    return sp, o, rsum
+
+
+def _gen_in_place(pomdp: CovidPOMDP, b: ParticleCollection, a: Action, seed: int, step: int):
+    """gen on the first particle of a collection that stays on the device between calls:
+    returns (o of the last sub-step, summed r)."""
     rsum, o = 0.0, 0
     for i in range(pomdp.test_period):
         ov, rv, _ = step_batch(b, a.testing_prop, seed=seed, step=step * pomdp.test_period + i)
         o, rsum = int(ov[0]), rsum + float(rv[0])
-    sp = b.particles[0]
-    b.close()
-    return sp, o, rsum
+    return o, rsum
 
 
 def observation(pomdp: CovidPOMDP, s: State, a: Action, sp: Optional[State] = None):
@@ -448,6 +455,7 @@ def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: Covid
     rewards = np.zeros(T)
     actions: List[Action] = []
     beliefs = []
+    true = ParticleCollection.from_states(single, [state], b.ctx.device)   # the true state stays on the device too
     for day in range(T):
         action = planner(b) if day % pomdp.test_period == 0 else actions[day - 1]
         sus[day], inf[day], rec[day] = state.S, int(state.I.sum()), state.R
@@ -457,7 +465,9 @@ def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: Covid
             beliefs.append(BeliefSummary(mean(b), qs, suminf_quantiles(b, qs)))
         elif keep_beliefs:
             beliefs.append(b.copy())
-        state, o, r = gen(single, state, action, seed=seed ^ 0x7275E, step=day)
+        o, r = _gen_in_place(single, true, action, seed ^ 0x7275E, day)
+        state = true.particles[0]
         b = update(upd, b, action, o)
         rewards[day], tests[day] = r, o
+    true.close()
     return SimHist(sus, inf, rec, pomdp.N, T, tests, actions, rewards, beliefs)
