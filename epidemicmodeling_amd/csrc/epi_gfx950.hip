@@ -279,7 +279,7 @@ __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A
 //   D  isolation bookkeeping per bin, attempt 0 of the gamma term; rejected -> queue
 //   E  gamma retry rounds
 //   F  infection sum in bin order, new infections, outputs
-// LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues.
+// LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues + three rotating entry counts.
 // ---------------------------------------------------------------------------
 #ifndef EPI_COOP_TPB
 #define EPI_COOP_TPB 256
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     double* gslots = reinterpret_cast<double*>(smem);                              // [H][CTPB]: gamma term of the bin's survivors
     unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * CTPB * 8);
     unsigned short* q1 = q0 + QCAP;
-    unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP);                 // qn[0], qn[1]
-    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 2);     // [CTPB/64]
+    unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP);                 // qn[0..2]: entry counts, rotating (+ 1 pad)
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
 
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * CTPB;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     const int32_t* __restrict__ in = (const int32_t*)in_u;
     int32_t* __restrict__ out = (int32_t*)out_u;
     const int64_t is = (int64_t)is_u, os = (int64_t)os_u;
-    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; }
+    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
     unsigned int flags = 0;
     int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
     unsigned long long code = 0ULL;
@@ -461,18 +461,20 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     }
 
     // ---- C: binomial retry rounds ------------------------------------------------------
+    // One barrier per round: round r reads the entries of queue (r-1) mod 2, counted in qn[(r-1) mod 3], and pushes
+    // its rejected draws to queue r mod 2, counted in qn[r mod 3]; thread 0 clears qn[(r+1) mod 3] for the round after
+    // (it was last read in round r-1, before this round's barrier).
     {
-        int cur = 0;
+        int cur = 0;                                                               // (round - 1) mod 3
 #pragma unroll 1
         for (uint32_t round = 1; round < BINOM_MAX_ATTEMPTS; round++) {
             __syncthreads();
             const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
-            __syncthreads();
             if (cnt == 0u) break;
-            if (tid == 0) qn[cur ^ 1] = 0u;
-            __syncthreads();
-            const unsigned short* q = cur ? q1 : q0;
-            unsigned short* qnext = cur ? q0 : q1;
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
+            const unsigned short* q = (round & 1u) ? q0 : q1;
+            unsigned short* qnext = (round & 1u) ? q1 : q0;
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
@@ -485,14 +487,14 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
                 int32_t k = btrs_attempt(C, wa, wb);
                 const bool fail = k < 0;
-                const bool pushed = q_push(fail, entry, qnext, &qn[cur ^ 1]);
+                const bool pushed = q_push(fail, entry, qnext, &qn[nxt]);
                 if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);
                 if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
             }
-            cur ^= 1;
+            cur = nxt;
         }
     }
-    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; }
+    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }                           // the count a slower thread may still be reading is zero already
     __syncthreads();
 
     // ---- D: isolation bookkeeping and attempt 0 of the gamma terms -------------------------
@@ -559,12 +561,11 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
         for (uint32_t round = 1; round < GAMMA_MAX_ATTEMPTS; round++) {
             __syncthreads();
             const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
-            __syncthreads();
             if (cnt == 0u) break;
-            if (tid == 0) qn[cur ^ 1] = 0u;
-            __syncthreads();
-            const unsigned short* q = cur ? q1 : q0;
-            unsigned short* qnext = cur ? q0 : q1;
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
+            const unsigned short* q = (round & 1u) ? q0 : q1;
+            unsigned short* qnext = (round & 1u) ? q1 : q0;
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
@@ -577,11 +578,11 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 gamma_retry(gt, (uint32_t)it, round, zf, wu);
                 double v;
                 const bool ok = gamma_attempt(G, zf, wu, v);
-                const bool pushed = q_push(!ok, entry, qnext, &qn[cur ^ 1]);
+                const bool pushed = q_push(!ok, entry, qnext, &qn[nxt]);
                 if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
                 else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
             }
-            cur ^= 1;
+            cur = nxt;
         }
     }
 
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     }
 }
 
-static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 2 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long); }
+static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long); }
 
 static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by state width, 2 cooperative
 
