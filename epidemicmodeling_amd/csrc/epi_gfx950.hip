@@ -817,13 +817,22 @@ __device__ __forceinline__ int64_t find_ancestor(const unsigned long long* __res
 struct BigRange { long long a, b; long long idx; };
 constexpr int SMALL_RANGE = 8, BIG_RANGE = 8192;
 
-// (inv_stepw ~ 1 / stepw only seeds the guess; the two loops make the result exact whatever its rounding)
+// a non-negative integer below 2^53 as a double (exact; three instructions instead of the general 64-bit conversion)
+__device__ __forceinline__ double exact_f64(unsigned long long x)
+{
+    return __builtin_fma((double)(uint32_t)(x >> 32), 4294967296.0, (double)(uint32_t)x);
+}
+
+// (inv_stepw ~ 1 / stepw only seeds the guess; the two loops make the result exact whatever its rounding.)
+// Cumulative weights and slot numbers are below 2^53, so the comparisons of floor(...) with c are made on doubles:
+// the same decisions as on the integers, without converting back.
 __device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw, double inv_stepw, double u, int64_t n_total)
 {
-    const double guess = __builtin_ceil((double)c * inv_stepw - u);
+    const double cd = exact_f64(c);
+    const double guess = __builtin_ceil(cd * inv_stepw - u);
     int64_t m = guess < 0.0 ? 0 : (guess > (double)n_total ? n_total : (int64_t)guess);
-    while (m > 0 && (unsigned long long)__builtin_floor(((double)(m - 1) + u) * stepw) >= c) m--;
-    while (m < n_total && (unsigned long long)__builtin_floor(((double)m + u) * stepw) < c) m++;
+    while (m > 0 && __builtin_floor((exact_f64((unsigned long long)(m - 1)) + u) * stepw) >= cd) m--;
+    while (m < n_total && __builtin_floor((exact_f64((unsigned long long)m) + u) * stepw) < cd) m++;
     return m;
 }
 

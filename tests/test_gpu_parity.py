@@ -116,6 +116,28 @@ def test_step_batch_bit_exact(pidx):
     assert (r.view(np.uint64) == er.view(np.uint64)).all()          # same IEEE operations: bitwise equal
 
 
+@pytest.mark.parametrize("n", [1, 2048, 2049, 8176, 8177])
+def test_step_batch_small_population_paths_bit_exact(n):
+    """Populations on either side of the sizes up to which transfers go through the context's page-locked staging
+    buffer (128 KB: 2048 particles of 16 rows for upload / download, 8176 particles for the step's outputs) and the
+    step's outputs live in the context's device scratch: the same results as the oracle on both paths, also with a
+    per-particle action (which takes device scratch too)."""
+    pomdp = em.make_pomdp(LOD=5)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    rng = np.random.default_rng(n)
+    st = random_states(pomdp, n, rng, scale=3000)
+    b = _belief(pomdp, st)
+    _eq(b.download(), st)
+    for step, a in enumerate((0.3, rng.random(n))):
+        a_prev = 0.1 if step == 0 else 0.3
+        o, r, fl = em.step_batch(b, a, a_prev, seed=SEED, step=step)
+        st, eo, er, eni, efl = orc.step_batch(st, np.broadcast_to(a, n).copy(), np.full(n, a_prev), seed=SEED, step=step)
+        _eq(b.download(), st)
+        assert (o == eo).all() and fl == efl
+        assert (r.view(np.uint64) == er.view(np.uint64)).all()
+    b.close()
+
+
 def test_step_variates_reproduce_the_step():
     """The recorded variates, injected into the deterministic step, give the same result."""
     pomdp = em.make_pomdp(LOD=5, test_delay=1)
