@@ -416,8 +416,8 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 bool fail = false;
                 if (cls == BINOM_INVERSION) x = binom_inversion(n, Dp->lnq[j][i], Dp->sr[j][i], wa);
                 else if (cls == BINOM_REJECTION) {
-                    const BtrsConsts C = btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen);
-                    x = btrs_attempt(C, wa, wb);
+                    BtrsConsts C;
+                    x = btrs_try(C, n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen, wa, wb);
                     fail = x < 0;
                 }
                 const int32_t res = fail ? n : (flip ? n - x : x);                 // a rejected draw keeps n for its retry
@@ -481,11 +481,11 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
                 const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
                 const bool flip = Dp->flip[j][i] != 0;                             // a queued draw is a rejection draw
-                const BtrsConsts C = btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wa, wb;
                 retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
-                int32_t k = btrs_attempt(C, wa, wb);
+                BtrsConsts C;
+                int32_t k = btrs_try(C, n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen, wa, wb);
                 const bool fail = k < 0;
                 const bool pushed = q_push(fail, entry, qnext, &qn[nxt]);
                 if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);

@@ -386,7 +386,7 @@ EPI_HD_OUTLINE int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t
 }
 
 struct BtrsConsts {
-    double nd, pp, a, b, c, vr, alpha, m, lpq;
+    double nd, pp, a, b, c, vr, alpha, m, lpq, spq;
     LfTable lf;
 #ifdef EPI_HAVE_SCREEN
     double cfl;                     // floor(c), and below its fraction: the k estimate works on small numbers
@@ -395,28 +395,43 @@ struct BtrsConsts {
 #endif
 };
 
-// lpq = s_log(pp / (1 - pp)) (a per-probability constant, tabulated per age bin by the kernels)
-EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, double lpq, const LfTable& lf, bool screen)
+// The constants come in two parts, so that a kernel can start the table loads of the acceptance test between them:
+// btrs_consts_k fills what the candidate k needs, btrs_consts_rest the squeeze bound and the hat's area (one binary32
+// quotient).  lpq = s_log(pp / (1 - pp)) (a per-probability constant, tabulated per age bin by the kernels).
+EPI_HD void btrs_consts_k(BtrsConsts& C, int32_t n, double pp, double lpq, const LfTable& lf, bool screen)
 {
-    BtrsConsts C;
     C.nd = (double)n; C.pp = pp; C.lpq = lpq; C.lf = lf;
     // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
-    const double spq = (double)sqrt_rn((float)(C.nd * pp * (1.0 - pp)));
-    C.b = 1.15 + 2.53 * spq;
+    C.spq = (double)sqrt_rn((float)(C.nd * pp * (1.0 - pp)));
+    C.b = 1.15 + 2.53 * C.spq;
     C.a = -0.0873 + 0.0248 * C.b + 0.01 * pp;
     C.c = C.nd * pp + 0.5;
-    const double ib = (double)div_rn(1.0f, (float)C.b);
-    C.vr = 0.92 - 4.2 * ib;
-    C.alpha = (2.83 + 5.1 * ib) * spq;
     C.m = __builtin_floor((C.nd + 1.0) * pp);
 #ifdef EPI_HAVE_SCREEN
     C.scr = screen;
-    C.af = (float)C.a; C.bf = (float)C.b; C.alf = (float)C.alpha;
+    C.af = (float)C.a; C.bf = (float)C.b;
     C.cfl = __builtin_floor(C.c);
     C.cfr = (float)(C.c - C.cfl);
 #else
     (void)screen;
 #endif
+}
+
+EPI_HD void btrs_consts_rest(BtrsConsts& C)
+{
+    const double ib = (double)div_rn(1.0f, (float)C.b);
+    C.vr = 0.92 - 4.2 * ib;
+    C.alpha = (2.83 + 5.1 * ib) * C.spq;
+#ifdef EPI_HAVE_SCREEN
+    C.alf = (float)C.alpha;
+#endif
+}
+
+EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, double lpq, const LfTable& lf, bool screen)
+{
+    BtrsConsts C;
+    btrs_consts_k(C, n, pp, lpq, lf, screen);
+    btrs_consts_rest(C);
     return C;
 }
 
@@ -474,6 +489,24 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
     const double kd = btrs_k(C, u, us);
     if (kd < 0.0 || kd > C.nd) return -1;
     if (us >= 0.07 && v <= C.vr) return (int32_t)kd;
+#if defined(EPI_HAVE_SCREEN) && !defined(EPI_NO_LV_FIRST)
+    // the table loads of the right side are issued first and the binary32 estimate of the left side, which does not
+    // depend on them, is computed while they are in flight
+    if (C.nd < (double)C.lf.n) {
+        const double* __restrict__ t = C.lf.t;
+        const int32_t ni = (int32_t)C.nd, mi = (int32_t)C.m, ki = (int32_t)kd;
+        const double t0 = t[mi], t1 = t[ni - mi], t2 = t[ki], t3 = t[ni - ki];
+        const float lvf = btrs_lv_screen(C, us, v);
+        // with the screens switched off the band is infinite: every attempt takes the defining expression
+        const double guard = C.scr ? (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS) : __builtin_inf();
+        const double lvd = (double)lvf, lin = (kd - C.m) * C.lpq;
+        const double ub = ((t0 + t1) - (t2 + t3)) + lin;
+        const double diff = lvd - ub;
+        if (diff < -guard) return (int32_t)kd;
+        if (diff > guard) return -1;
+        return btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? (int32_t)kd : -1;
+    }
+#endif
     const double ub = btrs_ub(C, kd);
 #ifdef EPI_HAVE_SCREEN
     if (C.scr) {
@@ -486,6 +519,54 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
 #endif
     return btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? (int32_t)kd : -1;
 }
+
+#if defined(EPI_HAVE_SCREEN)
+// The constants and one attempt in the order that suits the device.  When every argument of the acceptance test lies
+// inside the log-factorial table, every lane runs one straight sequence: a wave executes the acceptance test of nearly
+// every draw anyway (some lane is outside the squeeze region), and without the branches the four table loads can be
+// issued as soon as k is known; the second part of the constants, the squeeze test and the binary32 estimate of the
+// left side are computed while the loads are in flight.  Same operations on the same values as btrs_consts +
+// btrs_attempt, hence the same result; C is complete on return (for btrs_finish).
+__device__ __forceinline__ int32_t btrs_try(BtrsConsts& C, int32_t n, double pp, double lpq, const LfTable& lf, bool screen,
+                                            uint32_t wa, uint32_t wb)
+{
+    btrs_consts_k(C, n, pp, lpq, lf, screen);
+#ifndef EPI_NO_BTRS_TRY
+    if (C.nd < (double)lf.n) {
+        const double u = u01_centred(wa);
+        const double us = 0.5 - __builtin_fabs(u);
+        const double kd = btrs_k(C, u, us);
+        const bool inr = !(kd < 0.0 || kd > C.nd);
+        const double* __restrict__ t = lf.t;
+        const int32_t ni = n, mi = (int32_t)C.m, ki = inr ? (int32_t)kd : 0;       // an out-of-range k is rejected below
+        const double t0 = t[mi], t1 = t[ni - mi], t2 = t[ki], t3 = t[ni - ki];
+        __builtin_amdgcn_sched_barrier(0);                                          // nothing below moves above the loads
+        btrs_consts_rest(C);
+        const double v = u01(wb);
+        const bool squeeze = us >= 0.07 && v <= C.vr;
+        const float lvf = btrs_lv_screen(C, us, v);
+        // with the screens switched off the band is infinite: every attempt outside the squeeze takes the defining expression
+        const double guard = C.scr ? (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS) : __builtin_inf();
+        const double lvd = (double)lvf, lin = (kd - C.m) * C.lpq;
+        const double ub = ((t0 + t1) - (t2 + t3)) + lin;
+        const double diff = lvd - ub;
+        const bool acc = squeeze || diff < -guard;
+        int32_t res = (inr && acc) ? ki : -1;
+        if (inr && !acc && !(diff > guard)) res = btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? ki : -1;
+        return res;
+    }
+#endif
+    btrs_consts_rest(C);
+    return btrs_attempt(C, wa, wb);
+}
+#else
+// (the host pass over the kernel bodies, and a host restatement, see the plain composition)
+EPI_HD int32_t btrs_try(BtrsConsts& C, int32_t n, double pp, double lpq, const LfTable& lf, bool screen, uint32_t wa, uint32_t wb)
+{
+    C = btrs_consts(n, pp, lpq, lf, screen);
+    return btrs_attempt(C, wa, wb);
+}
+#endif
 
 // Word pair of attempt `att` (>= 1) of a retry stream: block (att-1)/2, words (0,1) or (2,3).
 EPI_HD void retry_pair(const Rng& g, uint32_t retry_kind, uint32_t bin, uint32_t att, uint32_t& wa, uint32_t& wb)
