@@ -411,6 +411,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 const int32_t n = j ? nn.y : nn.x;
                 const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];
                 int32_t x;
+#ifdef EPI_NO_BIN_RECORD
                 const int cls = binom_classify_tab(*Dp, j, i, n, x);
                 const bool flip = Dp->flip[j][i] != 0;
                 bool fail = false;
@@ -420,6 +421,23 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                     x = btrs_try(C, n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen, wa, wb);
                     fail = x < 0;
                 }
+#else
+                const BinConsts bc = Dp->bc[j][i];                                 // wave-uniform: scalar loads
+#ifndef EPI_NO_REC_PIN
+                // all of the record before the first branch: the loads go out together and are waited for once
+                // (left alone, each is sunk to its first use and waited for there: classification, threshold, rest)
+                asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.pp), "s"(bc.lpq), "s"(bc.lf_t), "s"(bc.lf_n));
+#endif
+                const int cls = binom_classify_rec(bc, n, x);
+                const bool flip = bc.flip != 0;
+                bool fail = false;
+                if (cls == BINOM_INVERSION) x = binom_inversion(n, bc.lnq, bc.sr, wa);
+                else if (cls == BINOM_REJECTION) {
+                    BtrsConsts C;
+                    x = btrs_try(C, n, bc.pp, bc.lpq, LfTable{bc.lf_t, bc.lf_n}, screen, wa, wb);
+                    fail = x < 0;
+                }
+#endif
                 const int32_t res = fail ? n : (flip ? n - x : x);                 // a rejected draw keeps n for its retry
                 if (j) nn.y = res; else nn.x = res;
                 failbits |= (unsigned int)fail << j;
@@ -480,12 +498,19 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 const unsigned short entry = q[e];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
                 const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
+#ifdef EPI_NO_BIN_RECORD
                 const bool flip = Dp->flip[j][i] != 0;                             // a queued draw is a rejection draw
+                const double pp = Dp->pp[j][i], lpq = Dp->lpq[j][i];
+#else
+                const BinConsts* __restrict__ bp = &Dp->bc[j][i];                  // the lane's record: adjacent loads
+                const double pp = bp->pp, lpq = bp->lpq;
+                const bool flip = bp->flip != 0;                                   // a queued draw is a rejection draw
+#endif
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wa, wb;
                 retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
                 BtrsConsts C;
-                int32_t k = btrs_try(C, n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen, wa, wb);
+                int32_t k = btrs_try(C, n, pp, lpq, Dp->lf, screen, wa, wb);
                 const bool fail = k < 0;
                 const bool pushed = q_push(fail, entry, qnext, &qn[nxt]);
                 if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);
@@ -1375,6 +1400,7 @@ int epi_params_set(epi_ctx* c, const epi_params* p)
     dp.P = *p;
     derive_params(dp);
     dp.lf = LfTable{c->d_lf, LF_TABLE_N};
+    pack_bin_consts(dp);
     HIPCHECK(hipMemcpy(c->d_params, &dp, sizeof dp, hipMemcpyHostToDevice));
     c->P = *p;
     c->have_params = true;

@@ -36,6 +36,15 @@ __host__ __device__ __forceinline__ int tests_row(int H, int r0, int c0) { retur
 
 // Parameters as the kernels read them (device memory): the caller's struct plus constants that
 // depend on the probabilities only, for both binomial draws of a bin (0: isolation, 1: positive test).
+// Everything one binomial draw of one age bin reads from the parameters, in one 64-byte record: the kernels fetch it
+// with a single wide scalar load (one wait) instead of a chain of dependent loads from the separate tables below.
+struct alignas(64) BinConsts {
+    double pp, lpq, lnq, sr;    // as in the tables below
+    const double* lf_t;         // the log-factorial table (same for every bin)
+    uint32_t nthr;
+    int32_t kind, flip, lf_n;
+};
+
 struct DevParams {
     epi_params P;
     double lnq[2][EPI_MAX_H];   // s_log(1 - pp), pp = min(p, 1 - p)
@@ -49,7 +58,28 @@ struct DevParams {
     int32_t kind[2][EPI_MAX_H];
     int32_t flip[2][EPI_MAX_H]; // p > 1/2: the draw is n - Binomial(n, 1 - p)
     LfTable lf;                 // tabulated log factorials (device memory; null on the host)
+    BinConsts bc[2][EPI_MAX_H]; // the same constants per (draw, bin); filled by pack_bin_consts once lf is set
 };
+
+inline void pack_bin_consts(DevParams& D)
+{
+    for (int j = 0; j < 2; j++)
+        for (int i = 0; i < EPI_MAX_H; i++) {
+            BinConsts& b = D.bc[j][i];
+            b.pp = D.pp[j][i]; b.lpq = D.lpq[j][i]; b.lnq = D.lnq[j][i]; b.sr = D.sr[j][i];
+            b.lf_t = D.lf.t; b.lf_n = D.lf.n;
+            b.nthr = D.nthr[j][i]; b.kind = D.kind[j][i]; b.flip = D.flip[j][i];
+        }
+}
+
+// binom_classify from one record (identical decisions)
+__host__ __device__ __forceinline__ int binom_classify_rec(const BinConsts& b, int32_t n, int32_t& result)
+{
+    result = 0;
+    if (n <= 0 || b.kind == 0) return BINOM_DONE;
+    if (b.kind == 1) { result = n; return BINOM_DONE; }
+    return (uint32_t)n < b.nthr ? BINOM_INVERSION : BINOM_REJECTION;
+}
 
 __host__ __device__ inline void derive_params(DevParams& D)
 {
