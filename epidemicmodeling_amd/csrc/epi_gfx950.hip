@@ -529,12 +529,27 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     float z_odd = 0.f;              // second normal / word of the pair block, for the odd term
     uint32_t w_odd = 0u;
     int32_t I_next = active ? in[(int64_t)(1 + H) * is + src] : 0;                 // bin H-1; loads run one bin ahead
+#ifndef EPI_NO_D_PREFETCH
+    int2 sp_next = slots[(H - 1) * CTPB + tid];                                    // so does the read of the bin's slot
+#endif
 #pragma unroll 1
     for (int it = 0; it < H; it++) {
         const int i = it == 0 ? H - 1 : it - 1;
         bool gfail = false;
+#ifndef EPI_NO_D_PREFETCH
+        // the term's Gamma parameters (wave-uniform) are requested at the top of the iteration, not at their first use
+        const double k_it = P.k[it], theta_it = P.theta[it];
+        asm volatile("" :: "s"(k_it), "s"(theta_it));
+#else
+        const double k_it = P.k[it], theta_it = P.theta[it];
+#endif
         if (active) {
+#ifndef EPI_NO_D_PREFETCH
+            const int2 sp = sp_next;
+            if (it + 1 < H) sp_next = slots[it * CTPB + tid];                      // bin of iteration it+1 (another slot than this bin's)
+#else
             const int2 sp = slots[i * CTPB + tid];
+#endif
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
             if (it + 1 < H) I_next = in[(int64_t)(2 + it) * is + src];             // bin of iteration it+1
@@ -554,7 +569,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             o_sum += pos;
             if (it == 0) R += Ii;                                                  // simulate.jl:144
             else { EPI_STREAM_STORE(&(out + ((int64_t)(2 + it) * os + base))[tid], Ii); sum_inf += Ii; }   // simulate.jl:145
-            const double shape = P.k[it] * (double)Ii;                             // init.jl:71-78
+            const double shape = k_it * (double)Ii;                                // init.jl:71-78
             float zf = z_odd;
             uint32_t wu = w_odd;
             if ((it & 1) == 0) {                                                   // an even term generates the block of its pair
@@ -568,7 +583,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
                 double v;
-                if (gamma_attempt(G, zf, wu, v)) gslots[i * CTPB + tid] = gamma_finish(G, v, P.theta[it], g, (uint32_t)it);
+                if (gamma_attempt(G, zf, wu, v)) gslots[i * CTPB + tid] = gamma_finish(G, v, theta_it, g, (uint32_t)it);
                 else { slots[i * CTPB + tid] = make_int2(Ii, 0); gfail = true; }
             }
         }
