@@ -411,23 +411,10 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 const int32_t n = j ? nn.y : nn.x;
                 const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];
                 int32_t x;
-#ifdef EPI_NO_BIN_RECORD
-                const int cls = binom_classify_tab(*Dp, j, i, n, x);
-                const bool flip = Dp->flip[j][i] != 0;
-                bool fail = false;
-                if (cls == BINOM_INVERSION) x = binom_inversion(n, Dp->lnq[j][i], Dp->sr[j][i], wa);
-                else if (cls == BINOM_REJECTION) {
-                    BtrsConsts C;
-                    x = btrs_try(C, n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen, wa, wb);
-                    fail = x < 0;
-                }
-#else
                 const BinConsts bc = Dp->bc[j][i];                                 // wave-uniform: scalar loads
-#ifndef EPI_NO_REC_PIN
                 // all of the record before the first branch: the loads go out together and are waited for once
                 // (left alone, each is sunk to its first use and waited for there: classification, threshold, rest)
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.pp), "s"(bc.lpq), "s"(bc.lf_t), "s"(bc.lf_n));
-#endif
                 const int cls = binom_classify_rec(bc, n, x);
                 const bool flip = bc.flip != 0;
                 bool fail = false;
@@ -437,7 +424,6 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                     x = btrs_try(C, n, bc.pp, bc.lpq, LfTable{bc.lf_t, bc.lf_n}, screen, wa, wb);
                     fail = x < 0;
                 }
-#endif
                 const int32_t res = fail ? n : (flip ? n - x : x);                 // a rejected draw keeps n for its retry
                 if (j) nn.y = res; else nn.x = res;
                 failbits |= (unsigned int)fail << j;
@@ -498,14 +484,9 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 const unsigned short entry = q[e];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
                 const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
-#ifdef EPI_NO_BIN_RECORD
-                const bool flip = Dp->flip[j][i] != 0;                             // a queued draw is a rejection draw
-                const double pp = Dp->pp[j][i], lpq = Dp->lpq[j][i];
-#else
                 const BinConsts* __restrict__ bp = &Dp->bc[j][i];                  // the lane's record: adjacent loads
                 const double pp = bp->pp, lpq = bp->lpq;
                 const bool flip = bp->flip != 0;                                   // a queued draw is a rejection draw
-#endif
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wa, wb;
                 retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
@@ -529,27 +510,17 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     float z_odd = 0.f;              // second normal / word of the pair block, for the odd term
     uint32_t w_odd = 0u;
     int32_t I_next = active ? in[(int64_t)(1 + H) * is + src] : 0;                 // bin H-1; loads run one bin ahead
-#ifndef EPI_NO_D_PREFETCH
     int2 sp_next = slots[(H - 1) * CTPB + tid];                                    // so does the read of the bin's slot
-#endif
 #pragma unroll 1
     for (int it = 0; it < H; it++) {
         const int i = it == 0 ? H - 1 : it - 1;
         bool gfail = false;
-#ifndef EPI_NO_D_PREFETCH
         // the term's Gamma parameters (wave-uniform) are requested at the top of the iteration, not at their first use
         const double k_it = P.k[it], theta_it = P.theta[it];
         asm volatile("" :: "s"(k_it), "s"(theta_it));
-#else
-        const double k_it = P.k[it], theta_it = P.theta[it];
-#endif
         if (active) {
-#ifndef EPI_NO_D_PREFETCH
             const int2 sp = sp_next;
             if (it + 1 < H) sp_next = slots[it * CTPB + tid];                      // bin of iteration it+1 (another slot than this bin's)
-#else
-            const int2 sp = slots[i * CTPB + tid];
-#endif
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
             if (it + 1 < H) I_next = in[(int64_t)(2 + it) * is + src];             // bin of iteration it+1
