@@ -537,16 +537,24 @@ __device__ __forceinline__ int32_t btrs_try(BtrsConsts& C, int32_t n, double pp,
         const double us = 0.5 - __builtin_fabs(u);
         const double kd = btrs_k(C, u, us);
         const bool inr = !(kd < 0.0 || kd > C.nd);
-        const double* __restrict__ t = lf.t;
-        const int32_t ni = n, mi = (int32_t)C.m, ki = inr ? (int32_t)kd : 0;       // an out-of-range k is rejected below
-        const double t0 = t[mi], t1 = t[ni - mi], t2 = t[ki], t3 = t[ni - ki];
+        // global address space and unsigned 32-bit indices: base in scalar registers + 32-bit offset, no 64-bit address arithmetic
+        typedef const char __attribute__((address_space(1)))* GlobalBytes;
+        typedef const double __attribute__((address_space(1)))* GlobalDoubles;
+        const GlobalBytes t = (GlobalBytes)lf.t;
+        const uint32_t ni = (uint32_t)n, mi = (uint32_t)(int32_t)C.m;
+        const int32_t ki = inr ? (int32_t)kd : 0;                                   // an out-of-range k is rejected below
+        // (the table holds 2^20 doubles: byte offsets fit 32 bits)
+        const double t0 = *(GlobalDoubles)(t + (mi << 3)), t1 = *(GlobalDoubles)(t + ((ni - mi) << 3));
+        const double t2 = *(GlobalDoubles)(t + ((uint32_t)ki << 3)), t3 = *(GlobalDoubles)(t + ((ni - (uint32_t)ki) << 3));
         __builtin_amdgcn_sched_barrier(0);                                          // nothing below moves above the loads
         btrs_consts_rest(C);
         const double v = u01(wb);
         const bool squeeze = us >= 0.07 && v <= C.vr;
         const float lvf = btrs_lv_screen(C, us, v);
-        // with the screens switched off the band is infinite: every attempt outside the squeeze takes the defining expression
-        const double guard = C.scr ? (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS) : __builtin_inf();
+        // with the screens switched off the band is infinite (or NaN, which no comparison passes): every attempt outside the
+        // squeeze takes the defining expression.  `screen` is wave-uniform, so the two constants are chosen by scalar selects.
+        const float grel = screen ? BTRS_GUARD_REL : __builtin_inff(), gabs = screen ? BTRS_GUARD_ABS : __builtin_inff();
+        const double guard = (double)__builtin_fmaf(__builtin_fabsf(lvf), grel, gabs);
         const double lvd = (double)lvf, lin = (kd - C.m) * C.lpq;
         const double ub = ((t0 + t1) - (t2 + t3)) + lin;
         const double diff = lvd - ub;
