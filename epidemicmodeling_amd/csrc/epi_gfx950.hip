@@ -356,6 +356,9 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     const int32_t* __restrict__ in = (const int32_t*)in_u;
     int32_t* __restrict__ out = (int32_t*)out_u;
     const int64_t is = (int64_t)is_u, os = (int64_t)os_u;
+    // state rows: one coalesced 4-byte access per lane and row
+    auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
+    auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[tid], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
     unsigned int flags = 0;
     int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
@@ -363,16 +366,16 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
 
     // ---- A: stage the bins, observation moments -----------------------------------
     if (active) {
-        S = in[src]; R = in[is + src]; R_pre = R;
+        S = ld_in(0); R = ld_in(1); R_pre = R;
         double tm = 0.0, tv = 0.0;
-        int32_t I_next = in[(int64_t)2 * is + src];                                // loads run one bin ahead of their use
+        int32_t I_next = ld_in(2);                                                 // loads run one bin ahead of their use
 #pragma unroll 1
         for (int i = 0; i < H; i++) {
             const int32_t Ii = I_next;
-            if (i + 1 < H) I_next = in[(int64_t)(3 + i) * is + src];
+            if (i + 1 < H) I_next = ld_in(3 + i);
             int32_t already = 0;
             if (D > 0 && i >= 1)
-                for (int r = 0; r < D; r++) already += in[(int64_t)tests_row(H, r, i) * is + src];
+                for (int r = 0; r < D; r++) already += ld_in(tests_row(H, r, i));
             const double ntf = __builtin_floor((double)(Ii - already) * a);        // simulate.jl:78
             const int32_t nt = (int32_t)ntf;
             if (nt < 0) flags |= EPI_F_NEG_NT;
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     int32_t sum_inf = 0;
     float z_odd = 0.f;              // second normal / word of the pair block, for the odd term
     uint32_t w_odd = 0u;
-    int32_t I_next = active ? in[(int64_t)(1 + H) * is + src] : 0;                 // bin H-1; loads run one bin ahead
+    int32_t I_next = active ? ld_in(1 + H) : 0;                                    // bin H-1; loads run one bin ahead
     int2 sp_next = slots[(H - 1) * CTPB + tid];                                    // so does the read of the bin's slot
 #pragma unroll 1
     for (int it = 0; it < H; it++) {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             if (it + 1 < H) sp_next = slots[it * CTPB + tid];                      // bin of iteration it+1 (another slot than this bin's)
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
-            if (it + 1 < H) I_next = in[(int64_t)(2 + it) * is + src];             // bin of iteration it+1
+            if (it + 1 < H) I_next = ld_in(2 + it);                                // bin of iteration it+1
             double pr = (double)sympt / (double)Ii;                                // simulate.jl:104
             if (pr != pr) pr = 0.0;                                                // simulate.jl:105
             const double om = 1.0 - pr;
@@ -531,15 +534,15 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             for (int r = 0; r <= D; r++) {                                         // simulate.jl:110-126
                 int32_t tv;
                 if (r == D) tv = pos;
-                else tv = (i >= 1) ? in[(int64_t)tests_row(H, r, i) * is + src] : 0;
+                else tv = (i >= 1) ? ld_in(tests_row(H, r, i)) : 0;
                 const int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
                 if (r == 0) { R += ts; Ii -= ts; }
-                else if (i + 1 < H) EPI_STREAM_STORE(&(out + ((int64_t)tests_row(H, r - 1, i + 1) * os + base))[tid], ts);
+                else if (i + 1 < H) st_out(tests_row(H, r - 1, i + 1), ts);
             }
             if (Ii < 0) flags |= EPI_F_NEG_I;                                      // simulate.jl:117
             o_sum += pos;
             if (it == 0) R += Ii;                                                  // simulate.jl:144
-            else { EPI_STREAM_STORE(&(out + ((int64_t)(2 + it) * os + base))[tid], Ii); sum_inf += Ii; }   // simulate.jl:145
+            else { st_out(2 + it, Ii); sum_inf += Ii; }                            // simulate.jl:145
             const double shape = k_it * (double)Ii;                                // init.jl:71-78
             float zf = z_odd;
             uint32_t wu = w_odd;
@@ -606,9 +609,9 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
         else newi = (int32_t)__builtin_floor(((double)S / (double)denom) * infsum);             // simulate.jl:42-44
-        EPI_STREAM_STORE(&(out + ((int64_t)2 * os + base))[tid], newi);                         // simulate.jl:147
-        EPI_STREAM_STORE(&(out + base)[tid], S - newi);                                         // simulate.jl:148
-        EPI_STREAM_STORE(&(out + (os + base))[tid], R);
+        st_out(2, newi);                                                                        // simulate.jl:147
+        st_out(0, S - newi);                                                                    // simulate.jl:148
+        st_out(1, R);
         if (Ak->o_out) Ak->o_out[m] = o_sum;
         if (Ak->newinf_out) Ak->newinf_out[m] = newi;
         if (Ak->r_out) {
