@@ -850,20 +850,20 @@ __device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw
     return m;
 }
 
-__global__ __launch_bounds__(TPB) void k_scatter(int64_t n_local, const unsigned long long* __restrict__ cum, const DevScalars* __restrict__ scal,
+// W, off: the total weight of all shards and the cumulative weight of the shards before this one (the host knows
+// both when it launches this kernel); stepw = fl(W / n_total) and inv_stepw = fl(n_total / W) come from the host too
+// (the same two correctly rounded divisions), so that no thread repeats them.
+__global__ __launch_bounds__(TPB) void k_scatter(int64_t n_local, const unsigned long long* __restrict__ cum, unsigned long long W, unsigned long long off,
+                                                  double stepw, double inv_stepw,
                                                   int64_t n_total, double u, int64_t slot_lo, int64_t slot_hi, int64_t slot0,
                                                   int32_t* __restrict__ anc, unsigned long long* __restrict__ big_count, BigRange* __restrict__ big)
 {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     const bool act = i < n_local;
-    const unsigned long long W = scal->w_total;
     if (W == 0ULL) {                        // every weight zero: keep the particle in place
         if (act && slot0 + i >= slot_lo && slot0 + i < slot_hi) anc[i] = (int32_t)i;
         return;
     }
-    const double stepw = (double)W / (double)n_total;
-    const double inv_stepw = (double)n_total / (double)W;
-    const unsigned long long off = scal->w_off;
     const int lane = threadIdx.x & 63;
     int64_t b = slot_hi;
     if (act && i < n_local - 1) b = first_slot(off + cum[i], stepw, inv_stepw, u, n_total);
@@ -2116,11 +2116,12 @@ static int launch_weigh(epi_ctx* c, epi_belief* b)
 }
 
 // ancestors of the owned slots [slot_lo, slot_hi) from the local cumulative weights
-static int launch_scatter(epi_ctx* c, epi_belief* b, double u, int64_t slot_lo, int64_t slot_hi)
+static int launch_scatter(epi_ctx* c, epi_belief* b, unsigned long long W, unsigned long long off, double u, int64_t slot_lo, int64_t slot_hi)
 {
     HIPCHECK(hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream));
     BigRange* list = reinterpret_cast<BigRange*>(b->big + 2);
-    k_scatter<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, reinterpret_cast<const unsigned long long*>(b->lw), c->d_scal,
+    const double stepw = W ? (double)W / (double)b->n_total : 0.0, inv_stepw = W ? (double)b->n_total / (double)W : 0.0;
+    k_scatter<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, reinterpret_cast<const unsigned long long*>(b->lw), W, off, stepw, inv_stepw,
                                                                                b->n_total, u, slot_lo, slot_hi, b->slot0, b->anc, b->big, list);
     int64_t gx = ceil_div(slot_hi - slot_lo, (int64_t)TPB * 8);
     gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
@@ -2380,8 +2381,9 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
     rc = set_offsets(c, G, shard, w_shard);
     if (rc) return rc;
     const double u = resample_offset(seed, step);
-    const int64_t count = slot_end - slot_begin;
-    rc = launch_scatter(c, b, u, slot_begin, slot_end);
+    unsigned long long off = 0ULL, total = 0ULL;
+    for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
+    rc = launch_scatter(c, b, total, off, u, slot_begin, slot_end);
     if (rc) return rc;
     return EPI_OK;
 }
