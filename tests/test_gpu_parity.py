@@ -155,6 +155,31 @@ def test_step_variates_reproduce_the_step():
     _eq(dev, exp2)
 
 
+@pytest.mark.parametrize("delay", [0, 2])
+def test_recorded_variates_drive_the_transliterated_reference_step(delay):
+    """The check a Julia harness would make with the reference's own SimStep, with the statement-by-statement
+    numpy transliteration of src/simulate.jl:99-151 standing in for it (no Julia here): the device takes a
+    Philox-driven step and hands back the 3 H variates every particle drew; the transliterated step, fed those
+    draws in the reference's order (sympt[1..H], pos[1..H], gamma[1..H]), must arrive at the same integer
+    compartments, pending tests and new infections."""
+    from oracle import step_numpy as sn
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    rng = np.random.default_rng(77 + delay)
+    n, H, a = 400, pomdp.horizon, 0.27
+    st = random_states(pomdp, n, rng, scale=5000)
+    b = _belief(pomdp, st)
+    sy = np.empty((n, H), np.int64); po = np.empty((n, H), np.int64); ga = np.empty((n, H)); fl = C.c_uint32()
+    check(b.ctx.lib.epi_step_variates(b.ctx.handle, b.handle, a, SEED, 5, as_i64p(sy), as_i64p(po), as_f64p(ga), C.byref(fl)))
+    S2, I2, R2, T2 = b.download()
+    b.close()
+    S, I, R, T = st
+    for j in range(n):
+        eS, eI, eR, eT, eni, neg = sn.sim_step(int(S[j]), I[j], int(R[j]), T[j].T, a, pomdp.N, sy[j], po[j], ga[j])
+        assert (S2[j], R2[j]) == (eS, eR), j
+        assert (I2[j] == eI).all() and (T2[j].T == eT).all(), j
+        assert I2[j][0] == eni
+
+
 # ---------------------------------------------------------------------------
 # initial beliefs, mean, sample
 # ---------------------------------------------------------------------------
