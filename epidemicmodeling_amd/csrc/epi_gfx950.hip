@@ -319,7 +319,8 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 #define EPI_COOP_WAVES 4   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
                            // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 #endif
-template <bool WEIGH>
+// DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
+template <bool WEIGH, bool DELAY>
 __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     typedef const StepArgs __attribute__((address_space(4)))* KernArgs;
     const KernArgs Ak = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __align__(16) unsigned char smem[];
-    const int H = P.H, D = P.D;
+    const int H = P.H, D = DELAY ? P.D : 0;
     int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][CTPB]: (I_i, tested_i) -> (sympt_i, pos_i)
     int* slot_words = reinterpret_cast<int*>(smem);
     double* gslots = reinterpret_cast<double*>(smem);                              // [H][CTPB]: gamma term of the bin's survivors
@@ -657,10 +658,13 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
     const size_t lds = coop_lds_bytes(c->P.H);
     if (g_coop == 2 || (g_coop == 1 && lds <= 40 * 1024)) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        k_step_coop<WEIGH><<<dim3((unsigned)ceil_div(A.n, CTPB)), dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        const dim3 grid((unsigned)ceil_div(A.n, CTPB));
+        if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        else k_step_coop<WEIGH, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
         k_step<WEIGH, MODE_PHILOX><<<dim3((unsigned)ceil_div(A.n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
     }
