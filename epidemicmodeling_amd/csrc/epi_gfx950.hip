@@ -201,7 +201,7 @@ enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
 #ifndef EPI_THREAD_WAVES
 #define EPI_THREAD_WAVES 4   // 128 VGPRs; 13 % faster than the 144-VGPR, 3-wave allocation
 #endif
-template <bool WEIGH, int MODE>
+template <bool WEIGH, int MODE, bool DELAY = true>
 __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else {
             PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0.f, 0u};
-            res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
+            res = particle_step<DELAY>(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         }
         flags = res.flags;
         if constexpr (WEIGH) {
@@ -666,7 +666,9 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
         else k_step_coop<WEIGH, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
-        k_step<WEIGH, MODE_PHILOX><<<dim3((unsigned)ceil_div(A.n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        const dim3 grid((unsigned)ceil_div(A.n, TPB));
+        if (c->P.D > 0) k_step<WEIGH, MODE_PHILOX, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        else k_step<WEIGH, MODE_PHILOX, false><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
     }
     return hipGetLastError();
 }

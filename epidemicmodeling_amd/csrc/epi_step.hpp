@@ -209,13 +209,14 @@ struct BinOut { int32_t ipost; double mean, sd2; };
 
 // Process one age bin (0-based column i) of the isolation update.  Writes the
 // shifted pending-test rows of column i+1 and returns I_i after isolation.
-template <class Draws>
+// DELAY = false: the build for test_delay = 0, without the pending-test rows
+template <bool DELAY = true, class Draws>
 __device__ __forceinline__ BinOut process_bin(const epi_params& P, int i, const int32_t* __restrict__ in, int64_t in_stride, int64_t src,
                                               int32_t* __restrict__ out, int64_t out_stride, int64_t dst,
                                               double a, const Draws& draws, int32_t& R, int32_t& o_sum, uint32_t& flags,
                                               int32_t* __restrict__ pos_out, int64_t pos_stride)
 {
-    const int H = P.H, D = P.D;
+    const int H = P.H, D = DELAY ? P.D : 0;
     int32_t Ii = in[(int64_t)(2 + i) * in_stride + src];
     int32_t already = 0;
     if (D > 0 && i >= 1)
@@ -253,7 +254,7 @@ __device__ __forceinline__ BinOut process_bin(const epi_params& P, int i, const 
 
 // Full step of the particle stored at column `src` of `in`, written to column
 // `dst` of `out`.
-template <class Draws>
+template <bool DELAY = true, class Draws>
 __device__ __forceinline__ StepResult particle_step(const epi_params& P, const int32_t* __restrict__ in, int64_t in_stride, int64_t src,
                                                     int32_t* __restrict__ out, int64_t out_stride, int64_t dst,
                                                     double a, const Draws& draws,
@@ -275,7 +276,7 @@ __device__ __forceinline__ StepResult particle_step(const epi_params& P, const i
 #pragma unroll 1
     for (int it = 0; it < H; it++) {
         const int i = it == 0 ? H - 1 : it - 1;
-        BinOut bo = process_bin(P, i, in, in_stride, src, out, out_stride, dst, a, draws, R, res.o, res.flags, pos_out, pos_stride);
+        BinOut bo = process_bin<DELAY>(P, i, in, in_stride, src, out, out_stride, dst, a, draws, R, res.o, res.flags, pos_out, pos_stride);
         if (it == 0) {
             last = bo;
             R += bo.ipost;                                                         // simulate.jl:144
