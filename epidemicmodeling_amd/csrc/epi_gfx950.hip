@@ -653,8 +653,8 @@ template <bool WEIGH>
 static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
 {
     // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 15 four workgroups share a CU and it is
-    // the faster one (2.2 vs 1.6e9 particle-steps/s at H = 14); wider states leave it one or two workgroups per CU
-    // and the per-thread kernel wins (H = 28: 0.72 vs 0.88e9, H = 56: 0.25 vs 0.54e9).
+    // the faster one (rollouts at H = 14: 2.4 vs 2.0e9 particle-steps/s); wider states leave it one or two workgroups
+    // per CU and the per-thread kernel wins (H = 28: 0.72 vs 1.14e9, H = 56: 0.25 vs 0.70e9).
     const size_t lds = coop_lds_bytes(c->P.H);
     if (g_coop == 2 || (g_coop == 1 && lds <= 40 * 1024)) {
         if (lds > 64 * 1024) {
