@@ -320,7 +320,8 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
                            // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 #endif
 // DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
-template <bool WEIGH, bool DELAY>
+// HC > 0: the number of infection ages is this constant (the reference's default horizon has a build of its own).
+template <bool WEIGH, bool DELAY, int HC = 0>
 __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     typedef const StepArgs __attribute__((address_space(4)))* KernArgs;
     const KernArgs Ak = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __align__(16) unsigned char smem[];
-    const int H = P.H, D = DELAY ? P.D : 0;
+    const int H = HC ? HC : P.H, D = DELAY ? P.D : 0;
     int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][CTPB]: (I_i, tested_i) -> (sympt_i, pos_i)
     int* slot_words = reinterpret_cast<int*>(smem);
     double* gslots = reinterpret_cast<double*>(smem);                              // [H][CTPB]: gamma term of the bin's survivors
@@ -664,6 +665,7 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         }
         const dim3 grid((unsigned)ceil_div(A.n, CTPB));
         if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        else if (c->P.H == 14) k_step_coop<WEIGH, false, 14><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
         else k_step_coop<WEIGH, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
         const dim3 grid((unsigned)ceil_div(A.n, TPB));
