@@ -853,7 +853,11 @@ __device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw
     const double cd = exact_f64(c);
     const double guess = __builtin_ceil(cd * inv_stepw - u);
     int64_t m = guess < 0.0 ? 0 : (guess > (double)n_total ? n_total : (int64_t)guess);
+    // the guess is nearly always right: each loop evaluates its condition once and leaves (not to be unrolled: an
+    // unrolled body evaluates several candidates at once, all but one of them for nothing)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     while (m > 0 && __builtin_floor((exact_f64((unsigned long long)(m - 1)) + u) * stepw) >= cd) m--;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     while (m < n_total && __builtin_floor((exact_f64((unsigned long long)m) + u) * stepw) < cd) m++;
     return m;
 }
