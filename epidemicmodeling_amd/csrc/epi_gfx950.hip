@@ -411,7 +411,8 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             uint32_t w[4];
             rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
             unsigned int failbits = 0u;
-#pragma unroll 1
+            // both draws of the bin as straight code: no selects on j, and the scheduler can overlap the two
+#pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int32_t n = j ? nn.y : nn.x;
                 const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];

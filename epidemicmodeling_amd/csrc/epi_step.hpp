@@ -145,8 +145,8 @@ struct PhiloxDraws {
     {
         uint32_t w[4];
         rng_block(g, K_BINOM0, (uint32_t)bin, 0, w);
-        // one instance of the sampler code for both draws
-#pragma unroll 1
+        // both draws as straight code (no selects on j; the scheduler overlaps the two)
+#pragma unroll
         for (int j = 0; j < 2; j++) {
             const int32_t r = bin_binomial(*D, bin, j, j ? n_tested : n_inf, j ? w[2] : w[0], j ? w[3] : w[1], g, screen);
             if (j) pos = r; else sympt = r;
