@@ -715,9 +715,8 @@ __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restric
     for (int j = 0; j < SCAN_ITEMS; j++) {
         int64_t i = base + j;
         if (i < n) {
-            unsigned long long w = quantize(lw[i], lwmax, scale);
-            sum += w;
-            double wd = (double)w;
+            const double wd = __builtin_floor(s_exp(lw[i] - lwmax) * scale);     // quantize(), before its conversion
+            sum += (unsigned long long)wd;
             sq += wd * wd;
         }
     }
