@@ -201,7 +201,8 @@ enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
 #ifndef EPI_THREAD_WAVES
 #define EPI_THREAD_WAVES 4   // 128 VGPRs; 13 % faster than the 144-VGPR, 3-wave allocation
 #endif
-template <bool WEIGH, int MODE, bool DELAY = true>
+// SCREEN = true: the samplers' binary32 screens are on at compile time (production); false: the run-time flag decides
+template <bool WEIGH, int MODE, bool DELAY = true, bool SCREEN = false>
 __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A
             RecordingDraws d{PhiloxDraws{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0.f, 0u}, A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else {
-            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0.f, 0u};
+            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), SCREEN ? true : A.screen != 0, Dp, 0.f, 0u};
             res = particle_step<DELAY>(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         }
         flags = res.flags;
@@ -321,7 +322,9 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 #endif
 // DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
 // HC > 0: the number of infection ages is this constant (the reference's default horizon has a build of its own).
-template <bool WEIGH, bool DELAY, int HC = 0>
+// SCREEN: the rejection samplers use their binary32 screens (a compile-time constant in the production builds: the
+// flag only selects code, never a result; the builds without screens exist for the test that shows exactly that).
+template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true>
 __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     const int64_t arow = A.a_div > 1 ? m / A.a_div : m;
     const double a = active ? (A.a_dev ? A.a_dev[arow * A.a_row_stride + A.a_col] : A.a) : 0.0;
     const Rng g = rng_make(A.seed, A.slot0 + (uint64_t)m, A.step);
-    const bool screen = A.screen != 0;
+    const bool screen = SCREEN;
     // The row strides and base pointers arrive in one wide scalar load; copied into register pairs of their own,
     // a reload after a scalar-register spill restores two registers instead of the whole eight-register tuple.
     uint64_t in_u, out_u, is_u, os_u;
@@ -662,16 +665,19 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
         const dim3 grid((unsigned)ceil_div(A.n, CTPB));
-        if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        if (!A.screen) k_step_coop<WEIGH, true, 0, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        else if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
         else if (c->P.H == 14) k_step_coop<WEIGH, false, 14><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
         else k_step_coop<WEIGH, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
         const dim3 grid((unsigned)ceil_div(A.n, TPB));
-        if (c->P.D > 0) k_step<WEIGH, MODE_PHILOX, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
-        else k_step<WEIGH, MODE_PHILOX, false><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        if (!A.screen) k_step<WEIGH, MODE_PHILOX, true, false><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        else if (c->P.D > 0) k_step<WEIGH, MODE_PHILOX, true, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        else k_step<WEIGH, MODE_PHILOX, false, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
     }
     return hipGetLastError();
 }
