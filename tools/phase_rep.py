@@ -7,6 +7,10 @@ library; all but the last repetition discard their results) and builds it as csr
 Time the variants with
     EPI_GFX950_LIB=.../variants/libepi_repB.so EPI_REPS=1 python3 bench.py --steps 5 --warmup 17 --no-cpu
 and subtract the EPI_REPS=0 figure of the same variant: the difference is the phase's cost.
+
+The substitutions below are anchored on the kernel's text as it was when the per-phase figures of the design notes
+were taken (before the record loads, the fused first attempt and the specialised builds); on a later text the
+script stops at the first anchor it cannot find, which then needs bringing up to date.
 """
 import os, subprocess, sys
 
