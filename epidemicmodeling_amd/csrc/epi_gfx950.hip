@@ -194,6 +194,7 @@ struct StepArgs {
     // recorded variates (MODE_RECORD)
     int32_t* rec_sympt; int32_t* rec_pos; double* rec_gam;
     int screen;                 // 1: the rejection samplers may use their binary32 screens
+    int64_t block0;             // k_step_coop: index of the launch's first workgroup within the population
 };
 
 enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
@@ -324,7 +325,8 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 // HC > 0: the number of infection ages is this constant (the reference's default horizon has a build of its own).
 // SCREEN: the rejection samplers use their binary32 screens (a compile-time constant in the production builds: the
 // flag only selects code, never a result; the builds without screens exist for the test that shows exactly that).
-template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true>
+// FULL: the population fills every workgroup of the grid (no thread needs the bounds check).
+template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true, bool FULL = false>
 __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
@@ -343,9 +345,9 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
 
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * CTPB;
+    const int64_t base = ((int64_t)blockIdx.x + A.block0) * CTPB;
     const int64_t m = base + tid;
-    const bool active = m < A.n;
+    const bool active = FULL ? true : m < A.n;
     const int64_t src = active ? (A.anc ? (int64_t)A.anc[m] : m) : 0;
     const int64_t arow = A.a_div > 1 ? m / A.a_div : m;
     const double a = active ? (A.a_dev ? A.a_dev[arow * A.a_row_stride + A.a_col] : A.a) : 0.0;
@@ -671,7 +673,17 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         const dim3 grid((unsigned)ceil_div(A.n, CTPB));
         if (!A.screen) k_step_coop<WEIGH, true, 0, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
         else if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
-        else if (c->P.H == 14) k_step_coop<WEIGH, false, 14><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        else if (c->P.H == 14) {
+            // the workgroups that the population fills run the build without the per-thread bounds check; the last,
+            // partial one (if any) is a launch of its own
+            const int64_t full = A.n / CTPB;
+            if (full > 0) k_step_coop<WEIGH, false, 14, true, true><<<dim3((unsigned)full), dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+            if (A.n % CTPB != 0) {
+                StepArgs T = A;
+                T.block0 = full;
+                k_step_coop<WEIGH, false, 14><<<dim3(1), dim3(CTPB), lds, c->stream>>>(T, c->d_params);
+            }
+        }
         else k_step_coop<WEIGH, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
         const dim3 grid((unsigned)ceil_div(A.n, TPB));
