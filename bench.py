@@ -231,7 +231,7 @@ def main():
                    "sharding": f"by index over {args.gpus} rank(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                     "kernel": "k_step_coop<true, %s, %d, true>" % (("true", 0) if D > 0 else ("false", 14 if H == 14 else 0)), "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
+                     "kernel": ("k_step_coop<true, false, 14, true, true>" if (D == 0 and H == 14) else "k_step_coop<true, %s, 0, true, false>" % ("true" if D > 0 else "false")), "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
         "issue": issue,
         "diagnostics": diag,
     }
