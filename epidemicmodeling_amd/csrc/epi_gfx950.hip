@@ -291,6 +291,7 @@ __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A
 #endif
 constexpr int CTPB = EPI_COOP_TPB;               // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
 constexpr unsigned int QCAP = EPI_COOP_QCAP;
+static_assert(CTPB >= 64 && CTPB <= 256 && CTPB % 64 == 0, "queue entries hold 8 bits of thread index");
 
 // push `entry` for every lane that wants to (one LDS atomic per wave); false = queue full
 __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn)
