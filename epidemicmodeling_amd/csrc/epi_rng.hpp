@@ -87,7 +87,8 @@ EPI_HD void rng_block(const Rng& g, uint32_t kind, uint32_t bin, uint32_t blk, u
     philox4x32_10(g.c0, g.c1, g.c2, (kind << 24) | (bin << 8) | blk, g.k0, g.k1, w);
 }
 
-// uniform in (0,1): (w + 1/2) 2^-32, exact in binary64
+// uniform in (0,1): (w + 1/2) 2^-32, exact in binary64.  (EPI_U01_BITS builds the same value from the bits of
+// 1 + (w + 1/2) 2^-32 and one subtraction; measured slower on gfx950 on three occasions, kept as a build switch.)
 #ifdef EPI_U01_BITS
 EPI_HD double u01_plus1(uint32_t w)
 {
