@@ -51,3 +51,22 @@ def test_observation_moments():
     m, sd = observation(p, s, Action(0.5))
     probs = np.array(p.pos_test_probs)
     assert np.isclose(m, (500 * probs).sum()) and np.isclose(sd ** 2, (500 * probs * (1 - probs)).sum())
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """The bench line kept under profiles/ (written by bench.py on the GPU box) has the fields the measurement
+    contract names, and its derived figures are consistent with each other."""
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_final", "bench.json")
+    d = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "particle-steps/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and "workload" in d["config"]
+    n, r = d["config"]["particles"], d["roofline"]
+    assert np.isclose(d["value"], n / (d["ms_per_step"] * 1e-3), rtol=1e-9)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert np.isclose(r["achieved"], r["alg_bytes_per_particle_step"] * n / (r["kernel_ms"] * 1e-3) / 1e9, rtol=1e-9)
+    assert np.isclose(r["frac"], r["achieved"] / r["peak"]) and r["traffic"] > r["alg_bytes_per_particle_step"] * n * 0.9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
