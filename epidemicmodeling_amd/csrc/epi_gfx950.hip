@@ -368,6 +368,10 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[tid], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
+    // the cleared counts must be visible before any wave pushes to the queue (after phase B): the barrier stands here,
+    // where the waves of the workgroup still run together, and not between phases A and B, which only exchange data
+    // within a thread
+    __syncthreads();
     unsigned int flags = 0;
     int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
     unsigned long long code = 0ULL;
@@ -404,7 +408,6 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             code = order_code(lw);
         }
     }
-    __syncthreads();
 
     // ---- B: attempt 0 of both binomials of every bin --------------------------------
     // rejected draws are remembered in a bit mask (bit 2 i + j) and queued in one go after the loop: one
