@@ -797,6 +797,46 @@ def test_random_parameter_sets_bit_exact(seed):
     _eq(b.download(), exp)
 
 
+@pytest.mark.parametrize("mode", ["mixed", "tiny", "deep"])
+def test_vanishing_test_probabilities_bit_exact(mode):
+    """Test probabilities down to the subnormals: the variance terms n p (1 - p) then lie below the range in which a
+    square root can do without rescaling its argument, and parameter sets like these take the kernel that rescales.
+    `mixed`: ordinary bins dominate the variance; `tiny`: every term is below 2^-767; `deep`: every term is a
+    subnormal number or close to one.  The largest log weight and the fixed-point weight total (which
+    every log weight enters) are compared exactly, then two updates through the resampled belief."""
+    H = 14
+    p = np.array([0.4, 1e-250, 3e-300, 0.7, 5e-324, 2.2e-308, 1e-211, 0.05, 1e-230, 0.0, 1.0, 1e-305, 0.3, 1e-290])
+    if mode == "tiny":
+        p = np.where(p > 1e-200, 1e-240, p)
+    elif mode == "deep":
+        p = np.array([5e-324, 1e-320, 2.2e-308, 1e-310, 3e-312, 0.0, 3e-309, 4e-315, 1e-309, 6e-311, 2e-308, 1e-322, 7e-317, 9e-313])
+    pomdp = em.make_pomdp(horizon=H, pos_test_probs=list(p))
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 3000
+    st = random_states(pomdp, n, np.random.default_rng(77), scale=3000)
+    a = 0.35
+    _, mu, _ = orc.log_weights(st, a, 0)
+    obs = int(np.median(mu))
+    b = _belief(pomdp, st)
+    lib, ctx = b.ctx.lib, b.ctx
+    lwmax, wl, sq = C.c_double(), C.c_uint64(), C.c_double()
+    check(lib.epi_pf_predict(ctx.handle, b.handle, a, obs, SEED, 0, C.byref(lwmax)))
+    check(lib.epi_pf_weigh(ctx.handle, b.handle, lwmax.value, C.byref(wl), C.byref(sq), None))
+    _, info = orc.pf_update(st, a, obs, SEED, 0)
+    assert np.isfinite(lwmax.value) and wl.value > 0
+    assert lwmax.value == info["lwmax"] and wl.value == info["W"]
+    b.close()
+    b = _belief(pomdp, st)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    exp = st
+    for step in range(2):
+        em.update(upd, b, em.Action(a), obs)
+        exp, info = orc.pf_update(exp, a, obs, SEED, step)
+        assert upd.last_flags == info["flags"]
+        _eq(b.download(), exp)
+    b.close()
+
+
 def test_maximum_state_shape_bit_exact():
     """EPI_MAX_H = 64 infection ages with EPI_MAX_D = 7 days of test delay (507 state rows), population close
     to the int32 limit: plain steps, filter updates and the mean against the oracle."""
