@@ -563,7 +563,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
             if (it + 1 < H) I_next = ld_in(2 + it);                                // bin of iteration it+1
-            double pr = (double)sympt / (double)Ii;                                // simulate.jl:104
+            double pr = div_unscaled((double)sympt, (double)Ii);                   // simulate.jl:104
             if (pr != pr) pr = 0.0;                                                // simulate.jl:105
             const double om = 1.0 - pr;
             R += sympt; Ii -= sympt;                                               // simulate.jl:107-108
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
         const int64_t denom = P.N - (int64_t)R;
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
-        else newi = (int32_t)__builtin_floor(((double)S / (double)denom) * infsum);             // simulate.jl:42-44
+        else newi = (int32_t)__builtin_floor(div_unscaled((double)S, (double)denom) * infsum);  // simulate.jl:42-44
         st_out(2, newi);                                                                        // simulate.jl:147
         st_out(0, S - newi);                                                                    // simulate.jl:148
         st_out(1, R);

@@ -207,6 +207,26 @@ struct StepResult {
 
 struct BinOut { int32_t ipost; double mean, sd2; };
 
+// Binary64 quotient a / b of operands whose exponents are ordinary (here: integers below 2^31, or 0 / 0, which gives
+// NaN as the division does): the compiler's own expansion (reciprocal estimate, two Newton steps, quotient, residual
+// correction) without the two scaling instructions and the fix-up of special operands around it, which do nothing
+// for such operands.  Same steps in the same order: the same bits.  (Device code only; the host divides.)
+EPI_HD double div_unscaled(double a, double b)
+{
+#if defined(EPI_NO_SHORT_DIV) || !defined(__HIP_DEVICE_COMPILE__)
+    return a / b;
+#else
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-b, r1, 1.0);
+    const double r2 = __builtin_fma(r1, e1, r1);
+    const double q0 = a * r2;
+    const double res = __builtin_fma(-b, q0, a);
+    return __builtin_fma(res, r2, q0);
+#endif
+}
+
 // Process one age bin (0-based column i) of the isolation update.  Writes the
 // shifted pending-test rows of column i+1 and returns I_i after isolation.
 // DELAY = false: the build for test_delay = 0, without the pending-test rows
@@ -231,7 +251,7 @@ __device__ __forceinline__ BinOut process_bin(const epi_params& P, int i, const 
     bo.mean = ntf * pi;                                                        // POMDPsInterface.jl:19
     double sd = __builtin_sqrt(ntf * pi * (1.0 - pi));
     bo.sd2 = sd * sd;                                                          // POMDPsInterface.jl:20
-    double pr = (double)sympt / (double)Ii;                                    // simulate.jl:104
+    double pr = div_unscaled((double)sympt, (double)Ii);                       // simulate.jl:104
     if (pr != pr) pr = 0.0;                                                    // simulate.jl:105
     const double om = 1.0 - pr;
     R += sympt; Ii -= sympt;                                                   // simulate.jl:107-108
@@ -292,7 +312,7 @@ __device__ __forceinline__ StepResult particle_step(const epi_params& P, const i
     int32_t newi = 0;
     if (denom <= 0) res.flags |= EPI_F_BAD_DENOM;
     else {
-        double sprop = (double)S / (double)denom;                              // simulate.jl:42
+        double sprop = div_unscaled((double)S, (double)denom);                 // simulate.jl:42
         newi = (int32_t)__builtin_floor(sprop * infsum);                       // simulate.jl:44
     }
     out[(int64_t)2 * out_stride + dst] = newi;                                 // simulate.jl:147
