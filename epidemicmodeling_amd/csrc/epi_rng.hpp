@@ -102,6 +102,12 @@ EPI_HD double u01_plus1(uint32_t w)
 }
 EPI_HD double u01(uint32_t w) { return u01_plus1(w) - 1.0; }
 EPI_HD double u01_centred(uint32_t w) { return u01_plus1(w) - 1.5; }
+#elif defined(EPI_U01_FMA)
+// One fused multiply-add each: w 2^-32 + 2^-33 and w 2^-32 + (2^-33 - 1/2) are exact in binary64 (33 significant bits).
+// Two instructions fewer per pair of uniforms, yet slower (23.49 against 23.26 ms for the step kernel): the two
+// constants are not inline operands and take scalar registers that the sampler phases are short of.
+EPI_HD double u01(uint32_t w) { return __builtin_fma((double)w, 0x1p-32, 0x1p-33); }
+EPI_HD double u01_centred(uint32_t w) { return __builtin_fma((double)w, 0x1p-32, 0x1p-33 - 0.5); }
 #else
 EPI_HD double u01(uint32_t w) { return ((double)w + 0.5) * 0x1p-32; }
 EPI_HD double u01_centred(uint32_t w) { return u01(w) - 0.5; }
