@@ -73,17 +73,22 @@ def cpu_baseline(pomdp, seconds_target=12.0, threads=None, n=500_000):
     st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
     _, mu, _ = orc.log_weights(st, ACTION, 0)
     o = int(np.median(mu))
+    # the same days of the epidemic as the timed GPU updates: the belief starts again from the initial one every 20
+    # updates (later days, with the infection dying out under one repeated observation, draw less and cost less)
+    st0 = st
     t0 = time.perf_counter()
     updates = 0
     while True:
-        st, info = orc.pf_update(st, ACTION, o, SEED, updates)
+        if updates % 20 == 0:
+            st = st0
+        st, info = orc.pf_update(st, ACTION, o, SEED, updates % 20)
         updates += 1
-        if time.perf_counter() - t0 > seconds_target or updates >= 40:
+        if time.perf_counter() - t0 > seconds_target:
             break
     dt = time.perf_counter() - t0
     return {"value": n * updates / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{updates} complete updates of {n} particles (oracle/epi_oracle.c, OpenMP {threads} threads, "
-                      f"default parameters, a={ACTION})"}
+            "sample": f"{updates} complete updates of {n} particles in runs of 20 from the initial belief "
+                      f"(oracle/epi_oracle.c, OpenMP {threads} threads, default parameters, a={ACTION})"}
 
 
 def run_single(args):
