@@ -911,6 +911,20 @@ __device__ __forceinline__ int64_t first_slot(unsigned long long c, double stepw
     return m;
 }
 
+// The same for a population of fewer than 2^31 slots (every population one device holds): slot numbers in 32-bit
+// registers, converted by single instructions.
+__device__ __forceinline__ int32_t first_slot32(unsigned long long c, double stepw, double inv_stepw, double u, int32_t n_total)
+{
+    const double cd = exact_f64(c);
+    const double guess = __builtin_ceil(cd * inv_stepw - u);
+    int32_t m = guess < 0.0 ? 0 : (guess > (double)n_total ? n_total : (int32_t)guess);
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    while (m > 0 && __builtin_floor(((double)(m - 1) + u) * stepw) >= cd) m--;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    while (m < n_total && __builtin_floor(((double)m + u) * stepw) < cd) m++;
+    return m;
+}
+
 // W, off: the total weight of all shards and the cumulative weight of the shards before this one (the host knows
 // both when it launches this kernel); stepw = fl(W / n_total) and inv_stepw = fl(n_total / W) come from the host too
 // (the same two correctly rounded divisions), so that no thread repeats them.
@@ -988,21 +1002,29 @@ __global__ __launch_bounds__(TPB) void k_wcum_scatter(int64_t n, const double* _
     }
     const double stepw = (double)W / (double)n;
     const double inv_stepw = (double)n / (double)W;
-    int64_t a = base == 0 ? 0 : first_slot(off, stepw, inv_stepw, u, n);
-    a = a > n ? n : a;
+#ifdef EPI_SCATTER_SLOTS64
+    typedef int64_t Slot;
+#define EPI_FIRST_SLOT first_slot
+#else
+    typedef int32_t Slot;                                   // n < 2^31: the ancestor index is 32 bits wide
+#define EPI_FIRST_SLOT first_slot32
+#endif
+    const Slot ns = (Slot)n;
+    Slot a = base == 0 ? 0 : EPI_FIRST_SLOT(off, stepw, inv_stepw, u, ns);
+    a = a > ns ? ns : a;
 #pragma unroll 1
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const int64_t i = base + j;
-        int64_t b = a;
-        if (i < n) b = i == n - 1 ? n : first_slot(off + v[j], stepw, inv_stepw, u, n);
-        const int64_t len = b - a;
+        Slot b = a;
+        if (i < n) b = i == n - 1 ? ns : EPI_FIRST_SLOT(off + v[j], stepw, inv_stepw, u, ns);
+        const Slot len = b - a;
         if (len > 0 && len <= SMALL_RANGE)
-            for (int64_t k = 0; k < len; k++) anc[a + k] = (int32_t)i;
+            for (Slot k = 0; k < len; k++) anc[(int64_t)a + k] = (int32_t)i;
         unsigned long long mask = __ballot(len > SMALL_RANGE && len <= BIG_RANGE);
         while (mask) {
             const int l = __ffsll((long long)mask) - 1;
             mask &= mask - 1ULL;
-            const int64_t a_l = (int64_t)__shfl((unsigned int)(a >> 32), l, 64) << 32 | (int64_t)__shfl((unsigned int)a, l, 64);
+            const int64_t a_l = (int64_t)__shfl((unsigned int)((int64_t)a >> 32), l, 64) << 32 | (int64_t)__shfl((unsigned int)a, l, 64);
             const int len_l = __shfl((int)len, l, 64);
             const int idx_l = __shfl((int)i, l, 64);
             for (int k = lane; k < len_l; k += 64) anc[a_l + k] = idx_l;
