@@ -59,6 +59,17 @@ def observations(pomdp, count):
 _OMP_DEFAULT = None
 
 
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pomdp, seconds_target=12.0, threads=None, n=500_000):
     """The oracle's complete update (port of the reference algorithm, OpenMP) on a bounded sample."""
     import numpy as np
@@ -87,6 +98,7 @@ def cpu_baseline(pomdp, seconds_target=12.0, threads=None, n=500_000):
             break
     dt = time.perf_counter() - t0
     return {"value": n * updates / dt, "unit": "particle-steps/s", "cores": threads, "kind": "port",
+            "host_cpu": host_cpu_model(), "host_nproc": os.cpu_count(),
             "sample": f"{updates} complete updates of {n} particles in runs of 20 from the initial belief "
                       f"(oracle/epi_oracle.c, OpenMP {threads} threads, default parameters, a={ACTION})"}
 
@@ -126,24 +138,89 @@ def run_single(args):
     return pomdp, n, dt, ksum.value / max(kcnt.value, 1), dict(loglik=ll.value, ess=ess.value, flags=fl.value)
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` started without a launcher: this process starts the N ranks itself (fresh interpreters,
+    before anything here has touched a GPU), one device each, waits for all of them and hands on rank 0's JSON line.
+    Returns the exit status for the parent."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EPI_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return 1
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 did not print exactly one JSON line\n")
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def init_group(args):
+    """Join the process group of the launcher (torchrun or spawn_ranks) and check that it is the one asked for."""
+    import torch
+    import torch.distributed as dist
+    if "RANK" not in os.environ:          # --sharded on one GPU without a launcher: a group of one
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    rank = int(os.environ["RANK"])
+    # EPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # tensors are staged through the host); the measured configuration is nccl (RCCL), one GPU per rank
+    backend = os.environ.get("EPI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    local = int(os.environ.get("LOCAL_RANK", rank)) % max(ndev, 1)
+    if backend == "nccl":
+        if ndev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} devices, this host shows {ndev}")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        if ndev:
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend)
+    world = dist.get_world_size()
+    if world != args.gpus:
+        dist.destroy_process_group()
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
+    return rank, world, backend, local
+
+
+def run_launch_check(args):
+    """--launch-check: the ranks only meet, agree on a number and leave (no device work): what a host without GPUs
+    can verify of the multi-rank start-up."""
+    import torch
+    import torch.distributed as dist
+    rank, world, backend, _ = init_group(args)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    ok = float(t[0]) == world * (world + 1) / 2
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        return {"launch_check": ok, "n_gpus": args.gpus, "world_size": world, "backend": backend}
+    return None
+
+
 def run_sharded(args):
     import torch
     import torch.distributed as dist
     import epidemicmodeling_amd as em
     from epidemicmodeling_amd.distributed import ShardedFilter
 
-    if "RANK" not in os.environ:          # --sharded on one GPU without a launcher: a group of one
-        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    # EPI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
-    # tensors are staged through the host); the measured configuration is nccl (RCCL), one GPU per rank
-    backend = os.environ.get("EPI_BENCH_BACKEND", "nccl")
-    local = int(os.environ.get("LOCAL_RANK", rank)) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group(backend)
+    rank, world, backend, local = init_group(args)
     pomdp = em.make_pomdp()
     n = args.particles
     obs = observations(pomdp, args.warmup + args.steps) if rank == 0 else None
@@ -168,7 +245,7 @@ def run_sharded(args):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, kms = float(tt[0]), float(tt[1])
     dist.destroy_process_group()
-    return pomdp, n, dt, kms, dict(loglik=info["loglik"], ess=info["ess"], flags=info["flags"]), rank
+    return pomdp, n, dt, kms, dict(loglik=info["loglik"], ess=info["ess"], flags=info["flags"]), rank, world, backend
 
 
 def main():
@@ -182,7 +259,15 @@ def main():
                     help="use the sharded (torch.distributed) update even with one GPU, to measure its host overhead")
     ap.add_argument("--calibrate", action="store_true",
                     help="after the timed region, run one gather dispatch of known traffic (PMC calibration)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="start the ranks, check the process group and leave without device work")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+
+    # no launcher around us: start the ranks here, before this process touches a GPU
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     # libraries underneath (RCCL prints a version banner at start-up) write to stdout too: send everything to stderr
     # while the benchmark runs, so that stdout carries the JSON line and nothing else
@@ -190,9 +275,16 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    rank = 0
+    rank, world, backend = 0, 1, "none (one process, one device)"
+    if args.launch_check:
+        res = run_launch_check(args)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        if res is not None:
+            print(json.dumps(res), flush=True)
+        return
     if args.gpus > 1 or args.sharded:
-        pomdp, n, dt, kms, diag, rank = run_sharded(args)
+        pomdp, n, dt, kms, diag, rank, world, backend = run_sharded(args)
     else:
         pomdp, n, dt, kms, diag = run_single(args)
     if rank != 0:
@@ -200,7 +292,7 @@ def main():
     H, D = pomdp.horizon, pomdp.test_delay
     balg = alg_bytes_per_particle_step(H, D)
     value = n * args.steps / dt
-    n_launch = n // args.gpus                       # particles one launch of the fused kernel processes
+    n_launch = n // world                           # particles one launch of the fused kernel processes
     achieved = balg * n_launch / (kms * 1e-3) / 1e9 if kms > 0 else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -228,7 +320,7 @@ def main():
             issue = None
     out = {
         "metric": "particle-steps/sec (whole node) at 10^8 particles; % of HBM roofline",
-        "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus, "world_size": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "dtype_note": "int32 compartment counts in HBM; sampler and weight arithmetic in binary64", "data": "synthetic",
         "config": {"workload": "bootstrap particle-filter update (predict+weight+systematic resample)",

@@ -1,0 +1,54 @@
+"""bench.py starts and verifies its own ranks when no launcher is around it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def _json_line(out: bytes):
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    # no RANK in the environment: the parent starts two ranks itself (gloo, no device work)
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=_env(EPI_BENCH_BACKEND="gloo"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    res = _json_line(p.stdout)
+    assert res == {"launch_check": True, "n_gpus": 2, "world_size": 2, "backend": "gloo"}
+
+
+def test_bench_refuses_a_process_group_of_the_wrong_size():
+    # a launcher that started one rank although --gpus says two: every rank must fail, nothing may be printed
+    env = _env(EPI_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b"process group has 1 rank" in p.stderr
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_box_report_their_world_size():
+    # two ranks share the box's one GPU and exchange through gloo (RCCL wants one device per rank): the whole sharded
+    # bench path with a process group of two, started by bench.py itself
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--particles", "20000", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       env=_env(EPI_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    res = _json_line(p.stdout)
+    assert res["n_gpus"] == 2 and res["world_size"] == 2 and res["backend"] == "gloo"
+    assert res["config"]["particles"] == 20000 and res["value"] > 0
+    assert res["diagnostics"]["flags"] == 0
