@@ -77,6 +77,7 @@ struct DevScalars {
     unsigned int flags;
     unsigned int pad;
 };
+static_assert(sizeof(DevScalars) <= 256, "the scalars of an update live in a 256-byte slot");
 
 struct epi_ctx {
     int device = 0;
@@ -86,7 +87,6 @@ struct epi_ctx {
     epi_params P;
     bool have_params = false;
     bool tiny_p = false;                // some test probability lies in (0, 2^-700): see launch_step
-    DevScalars* d_scal = nullptr;
     DevParams* d_params = nullptr;      // parameters + derived per-bin constants, as the kernels read them
     double* d_lf = nullptr;             // lfact(k), k < LF_TABLE_N
     long long* d_sums = nullptr;        // 2 + H + (D+1) H column sums
@@ -116,6 +116,7 @@ struct epi_belief {
     unsigned long long* blocksum = nullptr;
     double* blocksq = nullptr;
     unsigned long long* big = nullptr;  // [0] = number of listed long child ranges, then the ranges (k_scatter)
+    DevScalars* scal = nullptr;         // the scalars of this belief's updates (maximum log weight, weight totals, step flags)
     int64_t nblocks = 0;
     int phase = PH_IDLE;
     int64_t halo_used = 0;
@@ -141,6 +142,9 @@ static const size_t PIN_BYTES = 128 << 10;
 static const size_t SMALL_BYTES = 128 << 10;
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// the list of child ranges longer than 8192 slots that the scatter kernels leave to k_scatter_big: a count, then at most
+// n / 8192 + 1 ranges of 24 bytes
+static inline size_t big_list_bytes(int64_t n) { return 16 + 24 * ((size_t)n / 8192 + 2); }
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -734,15 +738,11 @@ __device__ __forceinline__ unsigned long long quantize(double lw, double lwmax, 
     return (unsigned long long)__builtin_floor(s_exp(lw - lwmax) * scale);
 }
 
-__global__ void k_scal_reset(DevScalars* s)
-{
-    s->lwmax_bits = 0ULL; s->lwmax = 0.0; s->w_local = 0ULL; s->w_off = 0ULL; s->w_total = 0ULL; s->sumsq = 0.0;
-}
-// single-device update: the local maximum is the global one
-__global__ void k_scal_lwmax_local(DevScalars* s) { s->lwmax = s->lwmax_bits ? order_decode(s->lwmax_bits) : -__builtin_inf(); }
-__global__ void k_scal_total_local(DevScalars* s) { s->w_off = 0ULL; s->w_total = s->w_local; }
+// The code of the maximum log weight (lwmax_bits) is zero between updates: the belief's scalars are created zero and
+// k_wscan, the one kernel of an update that runs as a single workgroup after every reader of the code, clears it again.
+__device__ __forceinline__ double lwmax_decode(unsigned long long bits) { return bits ? order_decode(bits) : -__builtin_inf(); }
 // the device-side hand-over of the phased update: local maximum out, global maximum in, local totals out
-__global__ void k_scal_export_lwmax(const DevScalars* s, double* out) { out[0] = s->lwmax_bits ? order_decode(s->lwmax_bits) : -__builtin_inf(); }
+__global__ void k_scal_export_lwmax(const DevScalars* s, double* out) { out[0] = lwmax_decode(s->lwmax_bits); }
 __global__ void k_scal_import_lwmax(DevScalars* s, const double* in) { s->lwmax = in[0]; }
 __global__ void k_scal_export_totals(const DevScalars* s, double* out)
 {
@@ -750,12 +750,15 @@ __global__ void k_scal_export_totals(const DevScalars* s, double* out)
 }
 __global__ void k_scal_set_offsets(DevScalars* s, unsigned long long off, unsigned long long total) { s->w_off = off; s->w_total = total; }
 
+// LOCAL: the population lives on this device alone, so the local maximum log weight (still coded, as the step kernel's
+// atomics left it) is the global one; otherwise the caller has installed the global maximum in scal->lwmax.
+template <bool LOCAL>
 __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restrict__ lw, const DevScalars* __restrict__ scal, int F,
                                                unsigned long long* __restrict__ blocksum, double* __restrict__ blocksq)
 {
     __shared__ unsigned long long s_sum[TPB / 64];
     __shared__ double s_sq[TPB / 64];
-    const double lwmax = scal->lwmax;
+    const double lwmax = LOCAL ? lwmax_decode(scal->lwmax_bits) : scal->lwmax;
     const double scale = u2d((uint64_t)(F + 1023) << 52);
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     unsigned long long sum = 0ULL;
@@ -779,9 +782,11 @@ __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restric
     }
 }
 
-// one workgroup: exclusive scan of blocksum in place, totals to scal
+// one workgroup: exclusive scan of blocksum in place, totals to scal; also the update's housekeeping: the list of long
+// child ranges is emptied for the scatter kernel that follows, and the code of the maximum log weight is cleared for
+// the next update (local: the maximum is decoded first and the local weight total is the global one)
 __global__ __launch_bounds__(1024) void k_wscan(int64_t nb, unsigned long long* __restrict__ blocksum, const double* __restrict__ blocksq,
-                                                DevScalars* __restrict__ scal)
+                                                DevScalars* __restrict__ scal, unsigned long long* __restrict__ big_count, int local)
 {
     __shared__ unsigned long long s_w[16];
     __shared__ unsigned long long s_carry;
@@ -817,6 +822,9 @@ __global__ __launch_bounds__(1024) void k_wscan(int64_t nb, unsigned long long* 
         for (int w = 0; w < 16; w++) q += s_q[w];
         scal->w_local = s_carry;
         scal->sumsq = q;
+        if (local) { scal->lwmax = lwmax_decode(scal->lwmax_bits); scal->w_off = 0ULL; scal->w_total = s_carry; }
+        scal->lwmax_bits = 0ULL;
+        *big_count = 0ULL;
     }
 }
 
@@ -1402,8 +1410,6 @@ int epi_ctx_create(int device, epi_ctx** out)
     const int rc = [c]() -> int {
         HIPCHECK(hipStreamCreate(&c->own_stream));
         c->stream = c->own_stream;
-        HIPCHECK(hipMalloc((void**)&c->d_scal, 256));
-        HIPCHECK(hipMemset(c->d_scal, 0, 256));
         HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
         HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
         k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
@@ -1431,7 +1437,6 @@ int epi_ctx_destroy(epi_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->d_sums) (void)hipFree(c->d_sums);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_lf) (void)hipFree(c->d_lf);
@@ -1512,14 +1517,21 @@ int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief*
     if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)n_local);
     if (e == hipSuccess) e = hipMalloc((void**)&b->blocksum, sizeof(unsigned long long) * (size_t)b->nblocks);
     if (e == hipSuccess) e = hipMalloc((void**)&b->blocksq, sizeof(double) * (size_t)b->nblocks);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->big, 16 + 24 * ((size_t)n_local / 8192 + 2));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->big, big_list_bytes(n_local));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->scal, 256);
     if (e != hipSuccess) {
         epi_belief_destroy(b);
         return fail(EPI_ENOMEM, "epi_belief_create: hipMalloc failed: %s", hipGetErrorString(e));
     }
-    HIPCHECK(hipMemsetAsync(b->buf[0], 0, bytes, c->stream));
-    HIPCHECK(hipMemsetAsync(b->buf[1], 0, bytes, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
+    hipError_t z = hipMemsetAsync(b->buf[0], 0, bytes, c->stream);
+    if (z == hipSuccess) z = hipMemsetAsync(b->buf[1], 0, bytes, c->stream);
+    if (z == hipSuccess) z = hipMemsetAsync(b->scal, 0, 256, c->stream);
+    if (z == hipSuccess) z = hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream);
+    if (z == hipSuccess) z = hipStreamSynchronize(c->stream);
+    if (z != hipSuccess) {
+        epi_belief_destroy(b);
+        return fail(EPI_EHIP, "epi_belief_create: clearing the buffers failed: %s", hipGetErrorString(z));
+    }
     *out = b;
     return EPI_OK;
 }
@@ -1535,6 +1547,7 @@ int epi_belief_destroy(epi_belief* b)
     if (b->lw) (void)hipFree(b->lw);
     if (b->blocksum) (void)hipFree(b->blocksum);
     if (b->big) (void)hipFree(b->big);
+    if (b->scal) (void)hipFree(b->scal);
     if (b->blocksq) (void)hipFree(b->blocksq);
     delete b;
     return EPI_OK;
@@ -1701,21 +1714,20 @@ int epi_belief_init_simplex(epi_belief* b, uint64_t seed)
 
 
 // the context's scalars, read back through the page-locked staging buffer; waits for the stream
-static int read_scalars(epi_ctx* c, DevScalars* h)
+static int read_scalars(epi_ctx* c, const DevScalars* d, DevScalars* h)
 {
-    static_assert(sizeof(DevScalars) <= 256, "DevScalars outgrew its allocation");
-    HIPCHECK(hipMemcpyAsync(c->h_pin, c->d_scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipMemcpyAsync(c->h_pin, d, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     memcpy(h, c->h_pin, sizeof(DevScalars));
     return EPI_OK;
 }
 
-static int fetch_flags(epi_ctx* c, uint32_t* flags, bool reset)
+static int fetch_flags(epi_ctx* c, DevScalars* d, uint32_t* flags, bool reset)
 {
     DevScalars h;
-    if (int rs = read_scalars(c, &h)) return rs;
+    if (int rs = read_scalars(c, d, &h)) return rs;
     if (flags) *flags = h.flags;
-    if (reset) HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+    if (reset) HIPCHECK(hipMemsetAsync(&d->flags, 0, sizeof(unsigned int), c->stream));
     return EPI_OK;
 }
 
@@ -1751,7 +1763,7 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
         HIPCHECK(hipMemcpyAsync(dap, a_prev, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
         A.a_prev_dev = dap;
     }
-    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
     if (o_out && !(A.o_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
     if (r_out && !(A.r_out = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
     if (new_inf_out && !(A.newinf_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
@@ -1762,11 +1774,11 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
         int32_t* ho = reinterpret_cast<int32_t*>(hp + 256);
         int32_t* hn = ho + n;
         double* hr = reinterpret_cast<double*>(hp + 256 + 8 * (size_t)n);
-        HIPCHECK(hipMemcpyAsync(hp, c->d_scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipMemcpyAsync(hp, b->scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
         if (o_out) HIPCHECK(hipMemcpyAsync(ho, A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         if (new_inf_out) HIPCHECK(hipMemcpyAsync(hn, A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         if (r_out) HIPCHECK(hipMemcpyAsync(hr, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+        HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
         HIPCHECK(hipStreamSynchronize(c->stream));
         if (flags) *flags = reinterpret_cast<const DevScalars*>(hp)->flags;
         for (int64_t i = 0; i < n; i++) {
@@ -1779,7 +1791,7 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
         if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
         if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
         if (r_out) HIPCHECK(hipMemcpyAsync(r_out, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        rc = fetch_flags(c, flags, true);
+        rc = fetch_flags(c, b->scal, flags, true);
         if (rc) return rc;
         HIPCHECK(hipStreamSynchronize(c->stream));
     }
@@ -1829,7 +1841,7 @@ int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_part
         HIPCHECK(hipMemcpyAsync(da.p, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
         A.a_dev = da.as<double>();
     }
-    A.scal = c->d_scal; A.slot0 = (uint64_t)b->slot0;
+    A.scal = b->scal; A.slot0 = (uint64_t)b->slot0;
     A.inj_sympt = ds.as<int32_t>(); A.inj_pos = dp.as<int32_t>(); A.inj_gam = dg.as<double>();
     A.newinf_out = dni.as<int32_t>(); A.pos_out = dpo.as<int32_t>();
     k_step<false, MODE_INJECT><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
@@ -1846,7 +1858,7 @@ int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_part
         for (int64_t p = 0; p < n; p++)
             for (int i = 0; i < H; i++) pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
     }
-    rc = fetch_flags(c, flags, true);
+    rc = fetch_flags(c, b->scal, flags, true);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));
     b->cur ^= 1; b->has_anc = false;
@@ -1873,7 +1885,7 @@ int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32
     A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a; A.a_row_stride = 1;
-    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
     A.rec_sympt = ds.as<int32_t>(); A.rec_pos = dp.as<int32_t>(); A.rec_gam = dg.as<double>();
     k_step<false, MODE_RECORD><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
     HIPCHECK(hipGetLastError());
@@ -1889,7 +1901,7 @@ int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32
             pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
             gam_out[p * H + i] = hg[(size_t)i * (size_t)n + (size_t)p];
         }
-    rc = fetch_flags(c, flags, true);
+    rc = fetch_flags(c, b->scal, flags, true);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));
     b->cur ^= 1; b->has_anc = false;
@@ -1966,7 +1978,7 @@ int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, i
         if (t == 0) A.a_prev = a_prev0;                         // prev_action of the start state (typedef.jl:180,216)
         else if (act_per_particle) { A.a_prev_dev = dact.as<double>(); A.a_prev_col = pcol; }
         else A.a_prev = actions[pcol];
-        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
         if (hist) A.hist = dhist.as<int32_t>() + (size_t)t * 4 * (size_t)n;
         if (rew) A.r_out = drew.as<double>() + (size_t)t * (size_t)n;
         HIPCHECK(launch_step<false>(c, A));
@@ -1987,7 +1999,7 @@ int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, i
         for (int64_t p = 0; p < n; p++)
             for (int t = 0; t < T; t++) rew[p * T + t] = h[(size_t)t * (size_t)n + (size_t)p];
     }
-    rc = fetch_flags(c, flags, true);
+    rc = fetch_flags(c, b->scal, flags, true);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));
     return EPI_OK;
@@ -2027,7 +2039,7 @@ int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts
         A.a_dev = dact.as<double>(); A.a_row_stride = T; A.a_col = t; A.a_div = rollouts_per_seq;
         if (t == 0) A.a_prev = a_prev0;
         else { A.a_prev_dev = dact.as<double>(); A.a_prev_col = t - 1; }
-        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = 0; A.scal = c->d_scal;
+        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = 0; A.scal = start->scal;
         A.r_out = drew.as<double>();
         HIPCHECK(launch_step<false>(c, A));
         k_score_acc<<<grid, blk, 0, c->stream>>>(n, dacc.as<double>(), drew.as<double>(), scale, t == 0);
@@ -2036,7 +2048,7 @@ int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts
     k_score_mean<<<dim3((unsigned)ceil_div(n_seq, TPB)), blk, 0, c->stream>>>(n_seq, rollouts_per_seq, dacc.as<double>(), dscore.as<double>());
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(score, dscore.p, sizeof(double) * (size_t)n_seq, hipMemcpyDeviceToHost, c->stream));
-    rc = fetch_flags(c, flags, true);
+    rc = fetch_flags(c, start->scal, flags, true);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(c->stream));
     return EPI_OK;
@@ -2093,12 +2105,12 @@ int epi_ensemble_simulate(epi_ctx* c, epi_belief* b, int T, const double* action
         if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
         else A.a = actions[tcol];
         A.a_prev = a_prev0;                                   // rewards are not computed here
-        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = c->d_scal;
+        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
         A.hist = e->hist + (size_t)t * 4 * (size_t)n;
         HIPCHECK(launch_step<false>(c, A));
         b->cur ^= 1; b->has_anc = false;
     }
-    rc = fetch_flags(c, flags, true);
+    rc = fetch_flags(c, b->scal, flags, true);
     if (rc) { epi_ensemble_destroy(e); return rc; }
     HIPCHECK(hipStreamSynchronize(c->stream));
     *out = e;
@@ -2164,9 +2176,18 @@ int epi_pf_frac_bits(int64_t n_total)
     return F > 40 ? 40 : F;
 }
 
-static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
+// The device memory an update uses beyond the particles, their ancestor index and their log weights: the scalars, the
+// per-tile weight totals and the list of long child ranges.  Normally the belief's own (allocated with it).
+struct UpdateScratch {
+    DevScalars* scal;
+    unsigned long long* blocksum;
+    double* blocksq;
+    unsigned long long* big;
+};
+static inline UpdateScratch own_scratch(epi_belief* b) { return UpdateScratch{b->scal, b->blocksum, b->blocksq, b->big}; }
+
+static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true)
 {
-    k_scal_reset<<<1, 1, 0, c->stream>>>(c->d_scal);
     StepArgs A;
     memset(&A, 0, sizeof A);
     A.screen = g_screen;
@@ -2174,9 +2195,9 @@ static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a; A.a_row_stride = 1;
     A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0;
-    A.o = (double)o; A.lw = b->lw; A.scal = c->d_scal;
+    A.o = (double)o; A.lw = b->lw; A.scal = sc.scal;
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
-    if (c->timing) {
+    if (c->timing && timed) {
         HIPCHECK(hipEventCreate(&e0));
         HIPCHECK(hipEventCreate(&e1));
         c->timed.emplace_back(e0, e1);
@@ -2184,7 +2205,7 @@ static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
     HIPCHECK(hipEventRecord(e0, c->stream));
     HIPCHECK(launch_step<true>(c, A));
     HIPCHECK(hipEventRecord(e1, c->stream));
-    if (!c->timing) c->ev_valid = true;
+    if (!(c->timing && timed)) c->ev_valid = true;
     b->seed = seed; b->step = step;
     b->halo_used = 0;
     b->frac_bits = epi_pf_frac_bits(b->n_total);
@@ -2193,17 +2214,17 @@ static int launch_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
 
 static int launch_weigh(epi_ctx* c, epi_belief* b)
 {
-    k_wsum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum, b->blocksq);
-    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, c->d_scal);
-    k_wcum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum);
+    k_wsum<false><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, b->blocksq);
+    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, b->scal, b->big, 0);
+    k_wcum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum);
     HIPCHECK(hipGetLastError());
     return EPI_OK;
 }
 
-// ancestors of the owned slots [slot_lo, slot_hi) from the local cumulative weights
+// ancestors of the owned slots [slot_lo, slot_hi) from the local cumulative weights (once per update: the list of long
+// child ranges is the one k_wscan emptied)
 static int launch_scatter(epi_ctx* c, epi_belief* b, unsigned long long W, unsigned long long off, double u, int64_t slot_lo, int64_t slot_hi)
 {
-    HIPCHECK(hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream));
     BigRange* list = reinterpret_cast<BigRange*>(b->big + 2);
     const double stepw = W ? (double)W / (double)b->n_total : 0.0, inv_stepw = W ? (double)b->n_total / (double)W : 0.0;
     k_scatter<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, reinterpret_cast<const unsigned long long*>(b->lw), W, off, stepw, inv_stepw,
@@ -2215,47 +2236,64 @@ static int launch_scatter(epi_ctx* c, epi_belief* b, unsigned long long W, unsig
     return EPI_OK;
 }
 
-int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
+static int update_checks(epi_ctx* c, epi_belief* b, const char* who)
 {
-    int rc = belief_check(b, "epi_pf_update");
+    int rc = belief_check(b, who);
     if (rc) return rc;
-    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_update: belief belongs to another context");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_update: a phased update is in progress");
-    if (b->n_total != b->n || b->slot0 != 0) return fail(EPI_ESTATE, "epi_pf_update: belief is a shard; use the phased calls");
-    HIPCHECK(hipSetDevice(c->device));
-    rc = launch_predict(c, b, a, o, seed, step);
+    if (!c || b->ctx != c) return fail(EPI_EINVAL, "%s: belief belongs to another context", who);
+    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "%s: a phased update is in progress", who);
+    if (b->n_total != b->n || b->slot0 != 0) return fail(EPI_ESTATE, "%s: belief is a shard; use the phased calls", who);
+    return EPI_OK;
+}
+
+// One whole update of a population held by one device, enqueued on the context's stream: step + weight, tile totals,
+// their scan, cumulative weights and ancestors in one pass, the long child ranges.  Five launches (six when the last
+// workgroup of the population is partial); nothing is allocated and the host does not wait.
+static int enqueue_update(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true)
+{
+    int rc = launch_predict(c, b, sc, a, o, seed, step, timed);
     if (rc) return rc;
-    k_scal_lwmax_local<<<1, 1, 0, c->stream>>>(c->d_scal);
     const double u = resample_offset(seed, step);
-    // weights -> tile totals -> scan of the totals -> cumulative weights and ancestors in one pass
-    HIPCHECK(hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream));
-    BigRange* list = reinterpret_cast<BigRange*>(b->big + 2);
-    k_wsum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum, b->blocksq);
-    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, c->d_scal);
-    k_scal_total_local<<<1, 1, 0, c->stream>>>(c->d_scal);
-    k_wcum_scatter<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, c->d_scal, b->frac_bits, b->blocksum, u, b->anc, b->big, list);
+    BigRange* list = reinterpret_cast<BigRange*>(sc.big + 2);
+    k_wsum<true><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, sc.scal, b->frac_bits, sc.blocksum, sc.blocksq);
+    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, sc.blocksum, sc.blocksq, sc.scal, sc.big, 1);
+    k_wcum_scatter<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, sc.scal, b->frac_bits, sc.blocksum, u, b->anc, sc.big, list);
     int64_t gx = ceil_div(b->n, (int64_t)TPB * 8);
     gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
-    k_scatter_big<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(b->big, list, 0, b->anc);
+    k_scatter_big<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(sc.big, list, 0, b->anc);
     HIPCHECK(hipGetLastError());
     b->cur ^= 1; b->has_anc = true;
     return EPI_OK;
 }
 
-int epi_pf_collect(epi_ctx* c, epi_belief* b, double* loglik, double* ess, uint32_t* flags)
+int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
 {
-    if (!c || !b) return fail(EPI_EINVAL, "epi_pf_collect: NULL argument");
+    int rc = update_checks(c, b, "epi_pf_update");
+    if (rc) return rc;
     HIPCHECK(hipSetDevice(c->device));
+    return enqueue_update(c, b, own_scratch(b), a, o, seed, step);
+}
+
+// diagnostics of the update whose scalars are `d`; waits for the stream, clears the flags
+static int collect_from(epi_ctx* c, epi_belief* b, DevScalars* d, double* loglik, double* ess, uint32_t* flags)
+{
     DevScalars h;
-    if (int rs = read_scalars(c, &h)) return rs;
+    if (int rs = read_scalars(c, d, &h)) return rs;
     uint32_t f = h.flags;
     if (h.w_total == 0ULL) f |= EPI_F_ZERO_W;
     if (flags) *flags = f;
-    HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+    HIPCHECK(hipMemsetAsync(&d->flags, 0, sizeof(unsigned int), c->stream));
     const double scale = ldexp(1.0, b->frac_bits);
     if (loglik) *loglik = h.w_total ? h.lwmax + log((double)h.w_total / scale / (double)b->n_total) - 0.91893853320467274178 : -INFINITY;
     if (ess) *ess = h.sumsq > 0.0 ? ((double)h.w_total * (double)h.w_total) / h.sumsq : 0.0;
     return EPI_OK;
+}
+
+int epi_pf_collect(epi_ctx* c, epi_belief* b, double* loglik, double* ess, uint32_t* flags)
+{
+    if (!c || !b || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_collect: bad argument");
+    HIPCHECK(hipSetDevice(c->device));
+    return collect_from(c, b, b->scal, loglik, ess, flags);
 }
 
 int epi_pf_update(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* loglik, double* ess, uint32_t* flags)
@@ -2356,10 +2394,10 @@ int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed
     if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_predict: belief belongs to another context");
     if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict: previous update not finished");
     HIPCHECK(hipSetDevice(c->device));
-    rc = launch_predict(c, b, a, o, seed, step);
+    rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
     if (rc) return rc;
     DevScalars h;
-    if (int rs = read_scalars(c, &h)) return rs;
+    if (int rs = read_scalars(c, b->scal, &h)) return rs;
     if (lwmax_local) *lwmax_local = h.lwmax_bits ? order_decode(h.lwmax_bits) : -INFINITY;
     b->phase = PH_PREDICTED;
     return EPI_OK;
@@ -2371,12 +2409,12 @@ int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_loc
     if (rc) return rc;
     if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh: call epi_pf_predict first");
     HIPCHECK(hipSetDevice(c->device));
-    HIPCHECK(hipMemcpyAsync(&c->d_scal->lwmax, &lwmax_global, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(&b->scal->lwmax, &lwmax_global, sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     rc = launch_weigh(c, b);
     if (rc) return rc;
     DevScalars h;
-    if (int rs = read_scalars(c, &h)) return rs;
+    if (int rs = read_scalars(c, b->scal, &h)) return rs;
     if (w_local) *w_local = h.w_local;
     if (sumsq_local) *sumsq_local = h.sumsq;
     if (flags_local) *flags_local = h.flags;
@@ -2391,9 +2429,9 @@ int epi_pf_predict_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t 
     if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_dev: bad argument");
     if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict_dev: previous update not finished");
     HIPCHECK(hipSetDevice(c->device));
-    rc = launch_predict(c, b, a, o, seed, step);
+    rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
     if (rc) return rc;
-    k_scal_export_lwmax<<<1, 1, 0, c->stream>>>(c->d_scal, d_lwmax_local);
+    k_scal_export_lwmax<<<1, 1, 0, c->stream>>>(b->scal, d_lwmax_local);
     HIPCHECK(hipGetLastError());
     b->phase = PH_PREDICTED;
     return EPI_OK;
@@ -2406,10 +2444,10 @@ int epi_pf_weigh_dev(epi_ctx* c, epi_belief* b, const double* d_lwmax_global, do
     if (!d_lwmax_global || !d_totals) return fail(EPI_EINVAL, "epi_pf_weigh_dev: NULL device pointer");
     if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh_dev: call epi_pf_predict_dev first");
     HIPCHECK(hipSetDevice(c->device));
-    k_scal_import_lwmax<<<1, 1, 0, c->stream>>>(c->d_scal, d_lwmax_global);
+    k_scal_import_lwmax<<<1, 1, 0, c->stream>>>(b->scal, d_lwmax_global);
     rc = launch_weigh(c, b);
     if (rc) return rc;
-    k_scal_export_totals<<<1, 1, 0, c->stream>>>(c->d_scal, d_totals);
+    k_scal_export_totals<<<1, 1, 0, c->stream>>>(b->scal, d_totals);
     HIPCHECK(hipGetLastError());
     b->phase = PH_WEIGHED;
     return EPI_OK;
@@ -2444,11 +2482,11 @@ int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, 
     return EPI_OK;
 }
 
-static int set_offsets(epi_ctx* c, int G, int shard, const uint64_t* w_shard)
+static int set_offsets(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard)
 {
     unsigned long long off = 0ULL, total = 0ULL;
     for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
-    k_scal_set_offsets<<<1, 1, 0, c->stream>>>(c->d_scal, off, total);
+    k_scal_set_offsets<<<1, 1, 0, c->stream>>>(b->scal, off, total);
     HIPCHECK(hipGetLastError());
     return EPI_OK;
 }
@@ -2463,7 +2501,7 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
         return fail(EPI_EINVAL, "epi_pf_select_local: slots [%lld, %lld) not owned by this shard", (long long)slot_begin, (long long)slot_end);
     if (slot_begin == slot_end) return EPI_OK;
     HIPCHECK(hipSetDevice(c->device));
-    rc = set_offsets(c, G, shard, w_shard);
+    rc = set_offsets(c, b, G, shard, w_shard);
     if (rc) return rc;
     const double u = resample_offset(seed, step);
     unsigned long long off = 0ULL, total = 0ULL;
@@ -2482,13 +2520,13 @@ int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w
     if (slot_begin > slot_end || slot_begin < 0 || slot_end > b->n_total || !dev_buf) return fail(EPI_EINVAL, "epi_pf_export: bad slot range or NULL buffer");
     if (slot_begin == slot_end) return EPI_OK;
     HIPCHECK(hipSetDevice(c->device));
-    rc = set_offsets(c, G, shard, w_shard);
+    rc = set_offsets(c, b, G, shard, w_shard);
     if (rc) return rc;
     const double u = resample_offset(seed, step);
     const int64_t count = slot_end - slot_begin;
     // the propagated particles of this update live in the buffer k_step wrote
     k_export<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin, b->slot0, reinterpret_cast<const unsigned long long*>(b->lw),
-                                                                             b->n, c->d_scal, b->n_total, u, b->buf[b->cur ^ 1], b->stride, b->rows,
+                                                                             b->n, b->scal, b->n_total, u, b->buf[b->cur ^ 1], b->stride, b->rows,
                                                                              static_cast<int32_t*>(dev_buf));
     HIPCHECK(hipGetLastError());
     if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
@@ -2521,9 +2559,9 @@ int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_finish: no update in progress");
     HIPCHECK(hipSetDevice(c->device));
     if (flags) {
-        rc = fetch_flags(c, flags, true);
+        rc = fetch_flags(c, b->scal, flags, true);
         if (rc) return rc;
-    } else HIPCHECK(hipMemsetAsync(&c->d_scal->flags, 0, sizeof(unsigned int), c->stream));
+    } else HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
     if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
     b->cur ^= 1; b->has_anc = true; b->phase = PH_IDLE;
     return EPI_OK;
