@@ -80,6 +80,7 @@ SIGNATURES = {
     "epi_ensemble_download": (C.c_int, [_vp, _i64p]),
     "epi_ensemble_loss": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_int, C.c_int, _f64p, _f64p]),
     "epi_pf_update": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p]),
+    "epi_pf_update_noalloc": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p]),
     "epi_pf_frac_bits": (C.c_int, [C.c_int64]),
     "epi_pf_predict": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p]),
     "epi_pf_weigh": (C.c_int, [_vp, _vp, C.c_double, _u64p, _f64p, _u32p]),

@@ -95,6 +95,7 @@ struct epi_ctx {
     // runs one call at a time, and every call that uses them has waited for the stream before it returns.
     unsigned char* h_pin = nullptr;     // PIN_BYTES of page-locked host memory
     unsigned char* d_small = nullptr;   // SMALL_BYTES of device scratch
+    unsigned char* d_static = nullptr;  // this device's copy of the file-scope scratch array of epi_pf_update_noalloc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     bool timing = false;                // record an event pair around every fused step kernel of an update
@@ -144,7 +145,7 @@ static const size_t SMALL_BYTES = 128 << 10;
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // the list of child ranges longer than 8192 slots that the scatter kernels leave to k_scatter_big: a count, then at most
 // n / 8192 + 1 ranges of 24 bytes
-static inline size_t big_list_bytes(int64_t n) { return 16 + 24 * ((size_t)n / 8192 + 2); }
+static constexpr size_t big_list_bytes(int64_t n) { return 16 + 24 * ((size_t)n / 8192 + 2); }
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -1391,6 +1392,8 @@ struct Arena {           // device scratch of one call: carved from the context'
     }
 };
 
+static int static_scratch_address(unsigned char** out);   // device address of epi_pf_update_noalloc's scratch array (below)
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -1420,7 +1423,7 @@ int epi_ctx_create(int device, epi_ctx** out)
         HIPCHECK(hipMalloc((void**)&c->d_small, SMALL_BYTES));
         HIPCHECK(hipEventCreate(&c->ev0));
         HIPCHECK(hipEventCreate(&c->ev1));
-        return EPI_OK;
+        return static_scratch_address(&c->d_static);
     }();
     if (rc != EPI_OK) {                 // release what was created before the failure (the message is already set)
         (void)epi_ctx_destroy(c);
@@ -2301,6 +2304,46 @@ int epi_pf_update(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed,
     int rc = epi_pf_update_async(c, b, a, o, seed, step);
     if (rc) return rc;
     return epi_pf_collect(c, b, loglik, ess, flags);
+}
+
+// ---- the update for callers that cannot allocate ---------------------------------------
+// epi_pf_update_noalloc runs the kernels of epi_pf_update with the update's scratch (scalars, per-tile weight totals
+// and sums of squares, the list of long child ranges) in a file-scope device array instead of the buffers a belief
+// allocates for them.  Every device the library runs on holds its own copy of the array, at its own address, until the
+// process ends; epi_ctx_create asks for that address once per context (with the context's device current) and host
+// code only ever uses that pointer, never the array's name.
+constexpr int64_t NOALLOC_MAX_PARTICLES = 1LL << 27;                 // 134 217 728: covers the 10^8-particle configuration
+constexpr size_t NA_TILES = (size_t)(NOALLOC_MAX_PARTICLES / SCAN_TILE);
+constexpr size_t NA_OFF_SUM = 256;                                   // after the DevScalars slot
+constexpr size_t NA_OFF_SQ = NA_OFF_SUM + 8 * NA_TILES;
+constexpr size_t NA_OFF_BIG = NA_OFF_SQ + 8 * NA_TILES;
+constexpr size_t NA_BYTES = (NA_OFF_BIG + big_list_bytes(NOALLOC_MAX_PARTICLES) + 255) & ~(size_t)255;   // 1.4 MB
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];
+
+static int static_scratch_address(unsigned char** out)
+{
+    HIPCHECK(hipGetSymbolAddress((void**)out, HIP_SYMBOL(scratch)));
+    return EPI_OK;
+}
+
+int epi_pf_update_noalloc(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* loglik, double* ess, uint32_t* flags)
+{
+    int rc = update_checks(c, b, "epi_pf_update_noalloc");
+    if (rc) return rc;
+    if (b->n > NOALLOC_MAX_PARTICLES)
+        return fail(EPI_ERANGE, "epi_pf_update_noalloc: %lld particles exceed the static scratch's maximum of %lld; use epi_pf_update",
+                    (long long)b->n, (long long)NOALLOC_MAX_PARTICLES);
+    if (!c->d_static) return fail(EPI_ESTATE, "epi_pf_update_noalloc: the context has no address for the static scratch");
+    HIPCHECK(hipSetDevice(c->device));
+    unsigned char* const p = c->d_static;
+    const UpdateScratch sc{reinterpret_cast<DevScalars*>(p), reinterpret_cast<unsigned long long*>(p + NA_OFF_SUM),
+                           reinterpret_cast<double*>(p + NA_OFF_SQ), reinterpret_cast<unsigned long long*>(p + NA_OFF_BIG)};
+    // the array keeps what the last call on this device left: the scalars (maximum code, flags) start from zero; the
+    // tile totals are overwritten before they are read and k_wscan empties the range list
+    HIPCHECK(hipMemsetAsync(p, 0, 256, c->stream));
+    rc = enqueue_update(c, b, sc, a, o, seed, step, false);
+    if (rc) return rc;
+    return collect_from(c, b, sc.scal, loglik, ess, flags);
 }
 
 int epi_debug_step_impl(int cooperative)

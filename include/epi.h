@@ -271,6 +271,18 @@ int epi_belief_suminf_quantiles(epi_ctx *ctx, epi_belief *b, const double *q, in
 int epi_belief_sample(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr,
                       int64_t *S, int64_t *I, int64_t *R, int64_t *T);
 
+/* ---- for callers that cannot allocate ------------------------------------------- */
+/* epi_pf_update for hosts that must not call hipMalloc while they run (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid it).  No counterpart in the reference.  Same arguments, same results bit
+ * for bit; the scratch of the update (scalars, per-tile weight totals, the list of long child ranges: 1.4 MB)
+ * lives in a file-scope device array of the library instead of buffers owned by the belief, so the call makes no
+ * hipMalloc / hipFree / hipEventCreate of any kind; results come back through the context's page-locked buffer.
+ * Limit: at most 2^27 = 134 217 728 particles (EPI_ERANGE beyond).  Every device holds one such array for the life of
+ * the process and every call on a device uses it: calls that overlap in time on one device (two contexts, two
+ * threads) race; calls in sequence do not.  The belief must be a whole population (not a shard). */
+int epi_pf_update_noalloc(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step,
+                          double *loglik, double *ess, uint32_t *flags);
+
 /* ---- introspection for benchmarks ------------------------------------------- */
 /* The context's HIP stream (hipStream_t) so that callers can bracket work with
  * their own events. */
