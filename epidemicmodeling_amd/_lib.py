@@ -100,15 +100,21 @@ SIGNATURES = {
     "epi_ctx_stream": (_vp, [_vp]),
     "epi_pf_update_async": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32]),
     "epi_pf_collect": (C.c_int, [_vp, _vp, _f64p, _f64p, _u32p]),
-    "epi_debug_screen": (C.c_int, [C.c_int]),
-    "epi_debug_step_impl": (C.c_int, [C.c_int]),
-    "epi_debug_f32_forms": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]),
     "epi_ctx_timing": (C.c_int, [_vp, C.c_int]),
     "epi_ctx_timing_read": (C.c_int, [_vp, _f64p, _i64p]),
     "epi_last_predict_ms": (C.c_float, [_vp]),
 }
 
+# the extra entry points of the testing build (include/epi_testing.h, libepi_gfx950_testing.so)
+TESTING_SIGNATURES = {
+    "epi_debug_screen": (C.c_int, [C.c_int]),
+    "epi_debug_step_impl": (C.c_int, [C.c_int]),
+    "epi_debug_f32_forms": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]),
+}
+TESTING_LIB_PATH = os.path.join(_HERE, "csrc", "libepi_gfx950_testing.so")
+
 _lib = None
+_testing_lib = None
 
 
 def load():
@@ -124,14 +130,29 @@ def load():
         lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise EpiLibraryError(f"cannot load {LIB_PATH}: {e}") from e
-    for name, (res, args) in SIGNATURES.items():
+    _set_prototypes(lib, SIGNATURES)
+    _lib = lib
+    return lib
+
+
+def _set_prototypes(lib, table):
+    for name, (res, args) in table.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if os.environ.get("EPI_STEP_IMPL"):            # A/B measurements: 0 per-thread, 1 by state width, 2 cooperative
-        lib.epi_debug_step_impl(int(os.environ["EPI_STEP_IMPL"]))
-    _lib = lib
-    return lib
+
+
+def load_testing():
+    """The build of the library with the switches of include/epi_testing.h (the test suite's own; never the default)."""
+    global _testing_lib
+    if _testing_lib is None:
+        if not os.path.exists(TESTING_LIB_PATH):
+            raise EpiLibraryError(f"{TESTING_LIB_PATH} not found: build it with `make -C epidemicmodeling_amd/csrc all`")
+        lib = C.CDLL(TESTING_LIB_PATH)
+        _set_prototypes(lib, SIGNATURES)
+        _set_prototypes(lib, TESTING_SIGNATURES)
+        _testing_lib = lib
+    return _testing_lib
 
 
 def check(rc: int):

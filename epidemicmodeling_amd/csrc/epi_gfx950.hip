@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <new>
 #include <string>
 #include <vector>
 #include "epi_step.hpp"
@@ -42,7 +43,16 @@ using namespace epi;
 // errors
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
+// The testing build (-DEPI_TESTING, libepi_gfx950_testing.so, declared in include/epi_testing.h) can switch the samplers'
+// binary32 screens off and force either implementation of the step kernel, to show that neither changes a result;
+// in the product both are constants and the alternative kernels are not even instantiated.
+#ifdef EPI_TESTING
 static int g_screen = 1;     // see epi_debug_screen
+static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by state width, 2 cooperative
+#else
+constexpr int g_screen = 1;
+constexpr int g_coop = 1;
+#endif
 
 static int fail(int code, const char* fmt, ...)
 {
@@ -53,6 +63,20 @@ static int fail(int code, const char* fmt, ...)
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// An entry point whose body allocates host memory (std::vector, new) runs inside guarded(): an exception must not
+// unwind through the C ABI into a ctypes or ccall frame, it becomes a status code.
+template <class F>
+static int guarded(const char* who, F&& body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc&) {
+        try { return fail(EPI_ENOMEM, "%s: host allocation failed", who); } catch (...) { return EPI_ENOMEM; }
+    }
+    catch (...) {
+        try { return fail(EPI_EINVAL, "%s: unexpected exception", who); } catch (...) { return EPI_EINVAL; }
+    }
 }
 
 #define HIPCHECK(expr)                                                                  \
@@ -205,12 +229,10 @@ struct StepArgs {
 
 enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
 
-#ifndef EPI_THREAD_WAVES
-#define EPI_THREAD_WAVES 4   // 128 VGPRs; 13 % faster than the 144-VGPR, 3-wave allocation
-#endif
+constexpr int THREAD_WAVES = 4;        // waves per SIMD the per-thread step kernel is allocated for (128 VGPRs; 13 % faster than 3 waves)
 // SCREEN = true: the samplers' binary32 screens are on at compile time (production); false: the run-time flag decides
 template <bool WEIGH, int MODE, bool DELAY = true, bool SCREEN = false>
-__global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A, const DevParams* __restrict__ Dp)
+__global__ __launch_bounds__(TPB, THREAD_WAVES) void k_step(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
     __shared__ unsigned long long s_max[TPB / 64];
@@ -289,15 +311,8 @@ __global__ __launch_bounds__(TPB, EPI_THREAD_WAVES) void k_step(const StepArgs A
 //   F  infection sum in bin order, new infections, outputs
 // LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues + three rotating entry counts.
 // ---------------------------------------------------------------------------
-#ifndef EPI_COOP_TPB
-#define EPI_COOP_TPB 256
-#endif
-#ifndef EPI_COOP_QCAP
-#define EPI_COOP_QCAP 2048
-#endif
-constexpr int CTPB = EPI_COOP_TPB;               // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
-constexpr unsigned int QCAP = EPI_COOP_QCAP;
-static_assert(CTPB >= 64 && CTPB <= 256 && CTPB % 64 == 0, "queue entries hold 8 bits of thread index");
+constexpr int CTPB = 256;                        // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
+constexpr unsigned int QCAP = 2048;              // entries per retry queue
 
 // Binary64 square root for arguments that are zero or at least 2^-767: the compiler's own expansion (reciprocal
 // square root estimate, one coupled Goldschmidt step, two residual corrections) without the pre- and post-scaling by
@@ -335,23 +350,17 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 
 // The posterior state and the log weights are written once and read by a later kernel: stored with the
 // non-temporal hint so that they do not displace the workgroups' spill lines and the tables from the L2.
-#ifdef EPI_NO_STREAM_HINT
-#define EPI_STREAM_STORE(ptr, val) (*(ptr) = (val))
-#else
 #define EPI_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#endif
 
-#ifndef EPI_COOP_WAVES
-#define EPI_COOP_WAVES 4   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
-                           // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
-#endif
+constexpr int COOP_WAVES = 4;   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
+                                // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 // DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
 // HC > 0: the number of infection ages is this constant (the reference's default horizon has a build of its own).
 // SCREEN: the rejection samplers use their binary32 screens (a compile-time constant in the production builds: the
 // flag only selects code, never a result; the builds without screens exist for the test that shows exactly that).
 // FULL: the population fills every workgroup of the grid (no thread needs the bounds check).
 template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true, bool FULL = false>
-__global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
+__global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
     const epi_params& P = Dp->P;
     // Arguments needed only at the end of the kernel are re-read from the kernel-argument segment there (scalar
@@ -420,13 +429,9 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
                 const double pi = P.p[i];
                 tm += ntf * pi;                                                    // POMDPsInterface.jl:19
                 if (pi > 0.0 && pi < 1.0) {                                        // else std = 0 exactly: nothing to add
-#ifdef EPI_NO_SHORT_SQRT
-                    const double sd = __builtin_sqrt(ntf * pi * (1.0 - pi));
-#else
                     // the launcher keeps parameter sets with a test probability below 2^-700 away from this kernel
                     // (a uniform branch on pi here costs more than the shorter form saves: 24.1 vs 23.4 ms)
                     const double sd = sqrt_unscaled(ntf * pi * (1.0 - pi));
-#endif
                     tv += sd * sd;                                                 // POMDPsInterface.jl:20
                 }
             }
@@ -686,8 +691,6 @@ __global__ __launch_bounds__(CTPB, EPI_COOP_WAVES) void k_step_coop(const StepAr
 
 static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long); }
 
-static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by state width, 2 cooperative
-
 // launch the Philox-driven step with the selected implementation
 template <bool WEIGH>
 static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
@@ -703,12 +706,17 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef EPI_TESTING
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, true, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
             if (e != hipSuccess) return e;
         }
         const dim3 grid((unsigned)ceil_div(A.n, CTPB));
+#ifdef EPI_TESTING
         if (!A.screen) k_step_coop<WEIGH, true, 0, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
-        else if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
+        else
+#endif
+        if (c->P.D > 0) k_step_coop<WEIGH, true><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
         else if (c->P.H == 14) {
             // the workgroups that the population fills run the build without the per-thread bounds check; the last,
             // partial one (if any) is a launch of its own
@@ -723,8 +731,11 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         else k_step_coop<WEIGH, false><<<grid, dim3(CTPB), lds, c->stream>>>(A, c->d_params);
     } else {
         const dim3 grid((unsigned)ceil_div(A.n, TPB));
+#ifdef EPI_TESTING
         if (!A.screen) k_step<WEIGH, MODE_PHILOX, true, false><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
-        else if (c->P.D > 0) k_step<WEIGH, MODE_PHILOX, true, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        else
+#endif
+        if (c->P.D > 0) k_step<WEIGH, MODE_PHILOX, true, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
         else k_step<WEIGH, MODE_PHILOX, false, true><<<grid, dim3(TPB), 0, c->stream>>>(A, c->d_params);
     }
     return hipGetLastError();
@@ -1011,21 +1022,15 @@ __global__ __launch_bounds__(TPB) void k_wcum_scatter(int64_t n, const double* _
     }
     const double stepw = (double)W / (double)n;
     const double inv_stepw = (double)n / (double)W;
-#ifdef EPI_SCATTER_SLOTS64
-    typedef int64_t Slot;
-#define EPI_FIRST_SLOT first_slot
-#else
     typedef int32_t Slot;                                   // n < 2^31: the ancestor index is 32 bits wide
-#define EPI_FIRST_SLOT first_slot32
-#endif
     const Slot ns = (Slot)n;
-    Slot a = base == 0 ? 0 : EPI_FIRST_SLOT(off, stepw, inv_stepw, u, ns);
+    Slot a = base == 0 ? 0 : first_slot32(off, stepw, inv_stepw, u, ns);
     a = a > ns ? ns : a;
 #pragma unroll 1
     for (int j = 0; j < SCAN_ITEMS; j++) {
         const int64_t i = base + j;
         Slot b = a;
-        if (i < n) b = i == n - 1 ? ns : EPI_FIRST_SLOT(off + v[j], stepw, inv_stepw, u, ns);
+        if (i < n) b = i == n - 1 ? ns : first_slot32(off + v[j], stepw, inv_stepw, u, ns);
         const Slot len = b - a;
         if (len > 0 && len <= SMALL_RANGE)
             for (Slot k = 0; k < len; k++) anc[(int64_t)a + k] = (int32_t)i;
@@ -1178,7 +1183,7 @@ __device__ __forceinline__ int32_t round_half_even(double x) { return (int32_t)_
 
 // State(Normal(mu, sigma), params): I_i = round(truncated-normal draw), S = N - sum I, R = 0
 __global__ __launch_bounds__(TPB) void k_init_normal(int64_t n, int32_t* __restrict__ out, int64_t stride, int H, int rows, long long N,
-                                                      double mu, double sigma, uint64_t seed, uint64_t slot0)
+                                                      double mu, double sigma, uint64_t seed, uint64_t slot0, unsigned int* __restrict__ over)
 {
     const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (m >= n) return;
@@ -1201,6 +1206,7 @@ __global__ __launch_bounds__(TPB) void k_init_normal(int64_t n, int32_t* __restr
     out[m] = (int32_t)(N - tot);
     out[stride + m] = 0;
     for (int r = 2 + H; r < rows; r++) out[(int64_t)r * stride + m] = 0;
+    if (tot > N) atomicOr(over, 1u);                         // typedef.jl:164 asserts sum(I0) <= N
 }
 
 // State(params): Bayesian-bootstrap split of N into (S, inf, R) and of inf into I[1..H]
@@ -1403,34 +1409,36 @@ int epi_state_rows(int H, int D) { return state_rows(H, D); }
 
 int epi_ctx_create(int device, epi_ctx** out)
 {
-    if (!out) return fail(EPI_EINVAL, "epi_ctx_create: out is NULL");
-    int ndev = 0;
-    HIPCHECK(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(EPI_EINVAL, "epi_ctx_create: device %d not in [0, %d)", device, ndev);
-    HIPCHECK(hipSetDevice(device));
-    epi_ctx* c = new epi_ctx();
-    c->device = device;
-    const int rc = [c]() -> int {
-        HIPCHECK(hipStreamCreate(&c->own_stream));
-        c->stream = c->own_stream;
-        HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
-        HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
-        k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
-        HIPCHECK(hipGetLastError());
-        HIPCHECK(hipStreamSynchronize(c->stream));
-        HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
-        HIPCHECK(hipHostMalloc((void**)&c->h_pin, PIN_BYTES, hipHostMallocDefault));
-        HIPCHECK(hipMalloc((void**)&c->d_small, SMALL_BYTES));
-        HIPCHECK(hipEventCreate(&c->ev0));
-        HIPCHECK(hipEventCreate(&c->ev1));
-        return static_scratch_address(&c->d_static);
-    }();
-    if (rc != EPI_OK) {                 // release what was created before the failure (the message is already set)
-        (void)epi_ctx_destroy(c);
-        return rc;
-    }
-    *out = c;
-    return EPI_OK;
+    return guarded("epi_ctx_create", [&]() -> int {
+        if (!out) return fail(EPI_EINVAL, "epi_ctx_create: out is NULL");
+        int ndev = 0;
+        HIPCHECK(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) return fail(EPI_EINVAL, "epi_ctx_create: device %d not in [0, %d)", device, ndev);
+        HIPCHECK(hipSetDevice(device));
+        epi_ctx* c = new epi_ctx();
+        c->device = device;
+        const int rc = [c]() -> int {
+            HIPCHECK(hipStreamCreate(&c->own_stream));
+            c->stream = c->own_stream;
+            HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
+            HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
+            k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
+            HIPCHECK(hipHostMalloc((void**)&c->h_pin, PIN_BYTES, hipHostMallocDefault));
+            HIPCHECK(hipMalloc((void**)&c->d_small, SMALL_BYTES));
+            HIPCHECK(hipEventCreate(&c->ev0));
+            HIPCHECK(hipEventCreate(&c->ev1));
+            return static_scratch_address(&c->d_static);
+        }();
+        if (rc != EPI_OK) {                 // release what was created before the failure (the message is already set)
+            (void)epi_ctx_destroy(c);
+            return rc;
+        }
+        *out = c;
+        return EPI_OK;
+    });
 }
 
 int epi_ctx_destroy(epi_ctx* c)
@@ -1438,6 +1446,8 @@ int epi_ctx_destroy(epi_ctx* c)
     if (!c) return EPI_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& pr : c->timed) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    c->timed.clear();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->d_sums) (void)hipFree(c->d_sums);
@@ -1464,29 +1474,31 @@ int epi_ctx_set_stream(epi_ctx* c, void* hip_stream, int adopt)
 
 int epi_params_set(epi_ctx* c, const epi_params* p)
 {
-    if (!c || !p) return fail(EPI_EINVAL, "epi_params_set: NULL argument");
-    if (p->H < 1 || p->H > EPI_MAX_H) return fail(EPI_EINVAL, "epi_params_set: H = %d not in [1, %d]", p->H, EPI_MAX_H);
-    if (p->D < 0 || p->D > EPI_MAX_D) return fail(EPI_EINVAL, "epi_params_set: test_delay D = %d not in [0, %d]", p->D, EPI_MAX_D);
-    if (p->N < 1 || p->N >= (1LL << 31)) return fail(EPI_ERANGE, "epi_params_set: N = %lld must be in [1, 2^31)", (long long)p->N);
-    for (int i = 0; i < p->H; i++) {
-        if (!(p->q[i] >= 0.0 && p->q[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: q[%d] = %g not a probability", i, p->q[i]);
-        if (!(p->p[i] >= 0.0 && p->p[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: p[%d] = %g not a probability", i, p->p[i]);
-        if (!(p->k[i] >= 0.0) || !(p->theta[i] >= 0.0)) return fail(EPI_EINVAL, "epi_params_set: Gamma parameters of bin %d negative", i);
-    }
-    HIPCHECK(hipSetDevice(c->device));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    DevParams dp;
-    memset(&dp, 0, sizeof dp);
-    dp.P = *p;
-    derive_params(dp);
-    dp.lf = LfTable{c->d_lf, LF_TABLE_N};
-    pack_bin_consts(dp);
-    HIPCHECK(hipMemcpy(c->d_params, &dp, sizeof dp, hipMemcpyHostToDevice));
-    c->P = *p;
-    c->have_params = true;
-    c->tiny_p = false;
-    for (int i = 0; i < p->H; i++) c->tiny_p |= p->p[i] > 0.0 && p->p[i] < 0x1p-700;
-    return EPI_OK;
+    return guarded("epi_params_set", [&]() -> int {
+        if (!c || !p) return fail(EPI_EINVAL, "epi_params_set: NULL argument");
+        if (p->H < 1 || p->H > EPI_MAX_H) return fail(EPI_EINVAL, "epi_params_set: H = %d not in [1, %d]", p->H, EPI_MAX_H);
+        if (p->D < 0 || p->D > EPI_MAX_D) return fail(EPI_EINVAL, "epi_params_set: test_delay D = %d not in [0, %d]", p->D, EPI_MAX_D);
+        if (p->N < 1 || p->N >= (1LL << 31)) return fail(EPI_ERANGE, "epi_params_set: N = %lld must be in [1, 2^31)", (long long)p->N);
+        for (int i = 0; i < p->H; i++) {
+            if (!(p->q[i] >= 0.0 && p->q[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: q[%d] = %g not a probability", i, p->q[i]);
+            if (!(p->p[i] >= 0.0 && p->p[i] <= 1.0)) return fail(EPI_EINVAL, "epi_params_set: p[%d] = %g not a probability", i, p->p[i]);
+            if (!(p->k[i] >= 0.0) || !(p->theta[i] >= 0.0)) return fail(EPI_EINVAL, "epi_params_set: Gamma parameters of bin %d negative", i);
+        }
+        HIPCHECK(hipSetDevice(c->device));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        DevParams dp;
+        memset(&dp, 0, sizeof dp);
+        dp.P = *p;
+        derive_params(dp);
+        dp.lf = LfTable{c->d_lf, LF_TABLE_N};
+        pack_bin_consts(dp);
+        HIPCHECK(hipMemcpy(c->d_params, &dp, sizeof dp, hipMemcpyHostToDevice));
+        c->P = *p;
+        c->have_params = true;
+        c->tiny_p = false;
+        for (int i = 0; i < p->H; i++) c->tiny_p |= p->p[i] > 0.0 && p->p[i] < 0x1p-700;
+        return EPI_OK;
+    });
 }
 
 // ---- beliefs -----------------------------------------------------------------
@@ -1502,41 +1514,43 @@ static int belief_check(const epi_belief* b, const char* who)
 
 int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief** out)
 {
-    if (!c || !out) return fail(EPI_EINVAL, "epi_belief_create: NULL argument");
-    if (!c->have_params) return fail(EPI_ESTATE, "epi_belief_create: epi_params_set has not been called");
-    if (n_local < 1 || halo_cap < 0) return fail(EPI_EINVAL, "epi_belief_create: n_local = %lld, halo_cap = %lld", (long long)n_local, (long long)halo_cap);
-    if (n_local + halo_cap >= (1LL << 31)) return fail(EPI_ERANGE, "epi_belief_create: n_local + halo_cap must be < 2^31");
-    HIPCHECK(hipSetDevice(c->device));
-    epi_belief* b = new epi_belief();
-    b->ctx = c; b->n = n_local; b->halo_cap = halo_cap;
-    b->stride = ceil_div(n_local + halo_cap, 64) * 64;          // rows start on 256-byte boundaries
-    b->n_total = n_local; b->slot0 = 0;
-    b->rows = state_rows(c->P.H, c->P.D);
-    b->nblocks = ceil_div(n_local, SCAN_TILE);
-    size_t bytes = sizeof(int32_t) * (size_t)b->rows * (size_t)b->stride;
-    hipError_t e = hipMalloc((void**)&b->buf[0], bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->buf[1], bytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->anc, sizeof(int32_t) * (size_t)n_local);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)n_local);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->blocksum, sizeof(unsigned long long) * (size_t)b->nblocks);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->blocksq, sizeof(double) * (size_t)b->nblocks);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->big, big_list_bytes(n_local));
-    if (e == hipSuccess) e = hipMalloc((void**)&b->scal, 256);
-    if (e != hipSuccess) {
-        epi_belief_destroy(b);
-        return fail(EPI_ENOMEM, "epi_belief_create: hipMalloc failed: %s", hipGetErrorString(e));
-    }
-    hipError_t z = hipMemsetAsync(b->buf[0], 0, bytes, c->stream);
-    if (z == hipSuccess) z = hipMemsetAsync(b->buf[1], 0, bytes, c->stream);
-    if (z == hipSuccess) z = hipMemsetAsync(b->scal, 0, 256, c->stream);
-    if (z == hipSuccess) z = hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream);
-    if (z == hipSuccess) z = hipStreamSynchronize(c->stream);
-    if (z != hipSuccess) {
-        epi_belief_destroy(b);
-        return fail(EPI_EHIP, "epi_belief_create: clearing the buffers failed: %s", hipGetErrorString(z));
-    }
-    *out = b;
-    return EPI_OK;
+    return guarded("epi_belief_create", [&]() -> int {
+        if (!c || !out) return fail(EPI_EINVAL, "epi_belief_create: NULL argument");
+        if (!c->have_params) return fail(EPI_ESTATE, "epi_belief_create: epi_params_set has not been called");
+        if (n_local < 1 || halo_cap < 0) return fail(EPI_EINVAL, "epi_belief_create: n_local = %lld, halo_cap = %lld", (long long)n_local, (long long)halo_cap);
+        if (n_local + halo_cap >= (1LL << 31)) return fail(EPI_ERANGE, "epi_belief_create: n_local + halo_cap must be < 2^31");
+        HIPCHECK(hipSetDevice(c->device));
+        epi_belief* b = new epi_belief();
+        b->ctx = c; b->n = n_local; b->halo_cap = halo_cap;
+        b->stride = ceil_div(n_local + halo_cap, 64) * 64;          // rows start on 256-byte boundaries
+        b->n_total = n_local; b->slot0 = 0;
+        b->rows = state_rows(c->P.H, c->P.D);
+        b->nblocks = ceil_div(n_local, SCAN_TILE);
+        size_t bytes = sizeof(int32_t) * (size_t)b->rows * (size_t)b->stride;
+        hipError_t e = hipMalloc((void**)&b->buf[0], bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->buf[1], bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->anc, sizeof(int32_t) * (size_t)n_local);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)n_local);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->blocksum, sizeof(unsigned long long) * (size_t)b->nblocks);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->blocksq, sizeof(double) * (size_t)b->nblocks);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->big, big_list_bytes(n_local));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->scal, 256);
+        if (e != hipSuccess) {
+            epi_belief_destroy(b);
+            return fail(EPI_ENOMEM, "epi_belief_create: hipMalloc failed: %s", hipGetErrorString(e));
+        }
+        hipError_t z = hipMemsetAsync(b->buf[0], 0, bytes, c->stream);
+        if (z == hipSuccess) z = hipMemsetAsync(b->buf[1], 0, bytes, c->stream);
+        if (z == hipSuccess) z = hipMemsetAsync(b->scal, 0, 256, c->stream);
+        if (z == hipSuccess) z = hipMemsetAsync(b->big, 0, sizeof(unsigned long long), c->stream);
+        if (z == hipSuccess) z = hipStreamSynchronize(c->stream);
+        if (z != hipSuccess) {
+            epi_belief_destroy(b);
+            return fail(EPI_EHIP, "epi_belief_create: clearing the buffers failed: %s", hipGetErrorString(z));
+        }
+        *out = b;
+        return EPI_OK;
+    });
 }
 
 int epi_belief_destroy(epi_belief* b)
@@ -1581,87 +1595,91 @@ static int materialize(epi_belief* b)
 
 int epi_belief_upload(epi_belief* b, const int64_t* S, const int64_t* I, const int64_t* R, const int64_t* T)
 {
-    int rc = belief_check(b, "epi_belief_upload");
-    if (rc) return rc;
-    if (!S || !I || !R) return fail(EPI_EINVAL, "epi_belief_upload: S, I, R must not be NULL");
-    epi_ctx* c = b->ctx;
-    const int H = c->P.H, D = c->P.D, D1 = D + 1;
-    const int64_t n = b->n;
-    HIPCHECK(hipSetDevice(c->device));
-    std::vector<int32_t> h((size_t)b->rows * (size_t)n);
-    const int64_t lim = (1LL << 31) - 1;
-    for (int64_t p = 0; p < n; p++) {
-        if (S[p] < -lim || S[p] > lim || R[p] < 0 || R[p] > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: S or R out of int32 range", (long long)p);
-        h[(size_t)p] = (int32_t)S[p];
-        h[(size_t)n + (size_t)p] = (int32_t)R[p];
-        for (int i = 0; i < H; i++) {
-            int64_t v = I[p * H + i];
-            if (v < 0 || v > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: I[%d] = %lld out of range", (long long)p, i, (long long)v);
-            h[(size_t)(2 + i) * (size_t)n + (size_t)p] = (int32_t)v;
-        }
-        if (T) {
-            const int64_t* Tp = T + p * D1 * H;
-            for (int cidx = 0; cidx < H; cidx++)
-                for (int r = 0; r < D1; r++) {
-                    int64_t v = Tp[cidx * D1 + r];
-                    bool live = (r < D) && (cidx >= 1);
-                    if (!live) {
-                        if (v != 0) return fail(EPI_EINVAL, "epi_belief_upload: particle %lld: Tests[%d,%d] = %lld but row D+1 and column 1 must be zero",
-                                                (long long)p, r + 1, cidx + 1, (long long)v);
-                    } else {
-                        if (v < 0 || v > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: Tests entry out of range", (long long)p);
-                        h[(size_t)tests_row(H, r, cidx) * (size_t)n + (size_t)p] = (int32_t)v;
+    return guarded("epi_belief_upload", [&]() -> int {
+        int rc = belief_check(b, "epi_belief_upload");
+        if (rc) return rc;
+        if (!S || !I || !R) return fail(EPI_EINVAL, "epi_belief_upload: S, I, R must not be NULL");
+        epi_ctx* c = b->ctx;
+        const int H = c->P.H, D = c->P.D, D1 = D + 1;
+        const int64_t n = b->n;
+        HIPCHECK(hipSetDevice(c->device));
+        std::vector<int32_t> h((size_t)b->rows * (size_t)n);
+        const int64_t lim = (1LL << 31) - 1;
+        for (int64_t p = 0; p < n; p++) {
+            if (S[p] < -lim || S[p] > lim || R[p] < 0 || R[p] > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: S or R out of int32 range", (long long)p);
+            h[(size_t)p] = (int32_t)S[p];
+            h[(size_t)n + (size_t)p] = (int32_t)R[p];
+            for (int i = 0; i < H; i++) {
+                int64_t v = I[p * H + i];
+                if (v < 0 || v > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: I[%d] = %lld out of range", (long long)p, i, (long long)v);
+                h[(size_t)(2 + i) * (size_t)n + (size_t)p] = (int32_t)v;
+            }
+            if (T) {
+                const int64_t* Tp = T + p * D1 * H;
+                for (int cidx = 0; cidx < H; cidx++)
+                    for (int r = 0; r < D1; r++) {
+                        int64_t v = Tp[cidx * D1 + r];
+                        bool live = (r < D) && (cidx >= 1);
+                        if (!live) {
+                            if (v != 0) return fail(EPI_EINVAL, "epi_belief_upload: particle %lld: Tests[%d,%d] = %lld but row D+1 and column 1 must be zero",
+                                                    (long long)p, r + 1, cidx + 1, (long long)v);
+                        } else {
+                            if (v < 0 || v > lim) return fail(EPI_ERANGE, "epi_belief_upload: particle %lld: Tests entry out of range", (long long)p);
+                            h[(size_t)tests_row(H, r, cidx) * (size_t)n + (size_t)p] = (int32_t)v;
+                        }
                     }
-                }
-        } else {
-            for (int r = 2 + H; r < b->rows; r++) h[(size_t)r * (size_t)n + (size_t)p] = 0;
+            } else {
+                for (int r = 2 + H; r < b->rows; r++) h[(size_t)r * (size_t)n + (size_t)p] = 0;
+            }
         }
-    }
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    HIPCHECK(hipMemcpy2D(b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, h.data(), sizeof(int32_t) * (size_t)n, sizeof(int32_t) * (size_t)n, (size_t)b->rows,
-                         hipMemcpyHostToDevice));
-    b->has_anc = false;
-    b->phase = PH_IDLE;
-    return EPI_OK;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        HIPCHECK(hipMemcpy2D(b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, h.data(), sizeof(int32_t) * (size_t)n, sizeof(int32_t) * (size_t)n, (size_t)b->rows,
+                             hipMemcpyHostToDevice));
+        b->has_anc = false;
+        b->phase = PH_IDLE;
+        return EPI_OK;
+    });
 }
 
 int epi_belief_download(epi_belief* b, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
 {
-    int rc = belief_check(b, "epi_belief_download");
-    if (rc) return rc;
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_download: a phased update is in progress");
-    epi_ctx* c = b->ctx;
-    const int H = c->P.H, D = c->P.D, D1 = D + 1;
-    const int64_t n = b->n;
-    HIPCHECK(hipSetDevice(c->device));
-    rc = materialize(b);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    // all rows in one strided copy; a small population comes back through the page-locked buffer
-    const size_t row_bytes = sizeof(int32_t) * (size_t)n;
-    std::vector<int32_t> hv;
-    const int32_t* h;
-    if (row_bytes * (size_t)b->rows <= PIN_BYTES) {
-        HIPCHECK(hipMemcpy2DAsync(c->h_pin, row_bytes, b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, row_bytes, (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
+    return guarded("epi_belief_download", [&]() -> int {
+        int rc = belief_check(b, "epi_belief_download");
+        if (rc) return rc;
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_download: a phased update is in progress");
+        epi_ctx* c = b->ctx;
+        const int H = c->P.H, D = c->P.D, D1 = D + 1;
+        const int64_t n = b->n;
+        HIPCHECK(hipSetDevice(c->device));
+        rc = materialize(b);
+        if (rc) return rc;
         HIPCHECK(hipStreamSynchronize(c->stream));
-        h = reinterpret_cast<const int32_t*>(c->h_pin);
-    } else {
-        hv.resize((size_t)b->rows * (size_t)n);
-        HIPCHECK(hipMemcpy2D(hv.data(), row_bytes, b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, row_bytes, (size_t)b->rows, hipMemcpyDeviceToHost));
-        h = hv.data();
-    }
-    for (int64_t p = 0; p < n; p++) {
-        if (S) S[p] = h[(size_t)p];
-        if (R) R[p] = h[(size_t)n + (size_t)p];
-        if (I) for (int i = 0; i < H; i++) I[p * H + i] = h[(size_t)(2 + i) * (size_t)n + (size_t)p];
-        if (T) {
-            int64_t* Tp = T + p * D1 * H;
-            for (int j = 0; j < D1 * H; j++) Tp[j] = 0;
-            for (int cidx = 1; cidx < H; cidx++)
-                for (int r = 0; r < D; r++) Tp[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx) * (size_t)n + (size_t)p];
+        // all rows in one strided copy; a small population comes back through the page-locked buffer
+        const size_t row_bytes = sizeof(int32_t) * (size_t)n;
+        std::vector<int32_t> hv;
+        const int32_t* h;
+        if (row_bytes * (size_t)b->rows <= PIN_BYTES) {
+            HIPCHECK(hipMemcpy2DAsync(c->h_pin, row_bytes, b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, row_bytes, (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            h = reinterpret_cast<const int32_t*>(c->h_pin);
+        } else {
+            hv.resize((size_t)b->rows * (size_t)n);
+            HIPCHECK(hipMemcpy2D(hv.data(), row_bytes, b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, row_bytes, (size_t)b->rows, hipMemcpyDeviceToHost));
+            h = hv.data();
         }
-    }
-    return EPI_OK;
+        for (int64_t p = 0; p < n; p++) {
+            if (S) S[p] = h[(size_t)p];
+            if (R) R[p] = h[(size_t)n + (size_t)p];
+            if (I) for (int i = 0; i < H; i++) I[p * H + i] = h[(size_t)(2 + i) * (size_t)n + (size_t)p];
+            if (T) {
+                int64_t* Tp = T + p * D1 * H;
+                for (int j = 0; j < D1 * H; j++) Tp[j] = 0;
+                for (int cidx = 1; cidx < H; cidx++)
+                    for (int r = 0; r < D; r++) Tp[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx) * (size_t)n + (size_t)p];
+            }
+        }
+        return EPI_OK;
+    });
 }
 
 int epi_belief_copy(epi_belief* dst, epi_belief* src)
@@ -1693,10 +1711,16 @@ int epi_belief_init_normal(epi_belief* b, double mu, double sigma, uint64_t seed
     if (!(sigma >= 0.0)) return fail(EPI_EINVAL, "epi_belief_init_normal: sigma = %g", sigma);
     epi_ctx* c = b->ctx;
     HIPCHECK(hipSetDevice(c->device));
-    k_init_normal<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, c->P.H, b->rows, (long long)c->P.N, mu, sigma, seed, (uint64_t)b->slot0);
+    unsigned int* over = reinterpret_cast<unsigned int*>(c->d_small);
+    HIPCHECK(hipMemsetAsync(over, 0, sizeof(unsigned int), c->stream));
+    k_init_normal<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, c->P.H, b->rows, (long long)c->P.N, mu, sigma, seed, (uint64_t)b->slot0, over);
     HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(c->h_pin, over, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
     b->has_anc = false; b->phase = PH_IDLE;
+    if (*reinterpret_cast<const unsigned int*>(c->h_pin))
+        return fail(EPI_EINVAL, "epi_belief_init_normal: a particle drew more initial infections than the population N = %lld "
+                                "(src/typedef.jl:164 asserts sum(I0) <= N)", (long long)c->P.N);
     return EPI_OK;
 }
 
@@ -1739,322 +1763,336 @@ static void widen(const std::vector<int32_t>& h, int64_t n, int64_t* out) { for 
 int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particle, const double* a_prev, int a_prev_per_particle,
                    uint64_t seed, uint32_t step, int64_t* o_out, double* r_out, int64_t* new_inf_out, uint32_t* flags)
 {
-    int rc = belief_check(b, "epi_step_batch");
-    if (rc) return rc;
-    if (!c || b->ctx != c || !a) return fail(EPI_EINVAL, "epi_step_batch: bad context or NULL action");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_batch: a phased update is in progress");
-    HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = b->n;
-    Arena scratch(c);
-    const char* nomem = "epi_step_batch: hipMalloc failed";
-    StepArgs A;
-    memset(&A, 0, sizeof A);
-    A.screen = g_screen;
-    A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
-    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
-    A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
-    if (a_per_particle) {
-        double* da = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n));
-        if (!da) return fail(EPI_ENOMEM, nomem);
-        HIPCHECK(hipMemcpyAsync(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        A.a_dev = da;
-    }
-    A.a_prev = a_prev ? a_prev[0] : 0.0;
-    if (a_prev && a_prev_per_particle) {
-        double* dap = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n));
-        if (!dap) return fail(EPI_ENOMEM, nomem);
-        HIPCHECK(hipMemcpyAsync(dap, a_prev, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        A.a_prev_dev = dap;
-    }
-    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
-    if (o_out && !(A.o_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
-    if (r_out && !(A.r_out = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
-    if (new_inf_out && !(A.newinf_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
-    HIPCHECK(launch_step<false>(c, A));
-    if ((size_t)n * 16 + 256 <= PIN_BYTES) {
-        // small population: outputs and scalars come back through the page-locked buffer with one wait
-        unsigned char* hp = c->h_pin;
-        int32_t* ho = reinterpret_cast<int32_t*>(hp + 256);
-        int32_t* hn = ho + n;
-        double* hr = reinterpret_cast<double*>(hp + 256 + 8 * (size_t)n);
-        HIPCHECK(hipMemcpyAsync(hp, b->scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
-        if (o_out) HIPCHECK(hipMemcpyAsync(ho, A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        if (new_inf_out) HIPCHECK(hipMemcpyAsync(hn, A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        if (r_out) HIPCHECK(hipMemcpyAsync(hr, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
-        if (flags) *flags = reinterpret_cast<const DevScalars*>(hp)->flags;
-        for (int64_t i = 0; i < n; i++) {
-            if (o_out) o_out[i] = ho[i];
-            if (new_inf_out) new_inf_out[i] = hn[i];
-            if (r_out) r_out[i] = hr[i];
-        }
-    } else {
-        std::vector<int32_t> h((size_t)n);
-        if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
-        if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
-        if (r_out) HIPCHECK(hipMemcpyAsync(r_out, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        rc = fetch_flags(c, b->scal, flags, true);
+    return guarded("epi_step_batch", [&]() -> int {
+        int rc = belief_check(b, "epi_step_batch");
         if (rc) return rc;
-        HIPCHECK(hipStreamSynchronize(c->stream));
-    }
-    b->cur ^= 1; b->has_anc = false;
-    return EPI_OK;
+        if (!c || b->ctx != c || !a) return fail(EPI_EINVAL, "epi_step_batch: bad context or NULL action");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_batch: a phased update is in progress");
+        HIPCHECK(hipSetDevice(c->device));
+        const int64_t n = b->n;
+        Arena scratch(c);
+        const char* nomem = "epi_step_batch: hipMalloc failed";
+        StepArgs A;
+        memset(&A, 0, sizeof A);
+        A.screen = g_screen;
+        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+        A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
+        if (a_per_particle) {
+            double* da = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n));
+            if (!da) return fail(EPI_ENOMEM, nomem);
+            HIPCHECK(hipMemcpyAsync(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            A.a_dev = da;
+        }
+        A.a_prev = a_prev ? a_prev[0] : 0.0;
+        if (a_prev && a_prev_per_particle) {
+            double* dap = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n));
+            if (!dap) return fail(EPI_ENOMEM, nomem);
+            HIPCHECK(hipMemcpyAsync(dap, a_prev, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            A.a_prev_dev = dap;
+        }
+        A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
+        if (o_out && !(A.o_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
+        if (r_out && !(A.r_out = static_cast<double*>(scratch.get(sizeof(double) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
+        if (new_inf_out && !(A.newinf_out = static_cast<int32_t*>(scratch.get(sizeof(int32_t) * (size_t)n)))) return fail(EPI_ENOMEM, nomem);
+        HIPCHECK(launch_step<false>(c, A));
+        if ((size_t)n * 16 + 256 <= PIN_BYTES) {
+            // small population: outputs and scalars come back through the page-locked buffer with one wait
+            unsigned char* hp = c->h_pin;
+            int32_t* ho = reinterpret_cast<int32_t*>(hp + 256);
+            int32_t* hn = ho + n;
+            double* hr = reinterpret_cast<double*>(hp + 256 + 8 * (size_t)n);
+            HIPCHECK(hipMemcpyAsync(hp, b->scal, sizeof(DevScalars), hipMemcpyDeviceToHost, c->stream));
+            if (o_out) HIPCHECK(hipMemcpyAsync(ho, A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            if (new_inf_out) HIPCHECK(hipMemcpyAsync(hn, A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            if (r_out) HIPCHECK(hipMemcpyAsync(hr, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            if (flags) *flags = reinterpret_cast<const DevScalars*>(hp)->flags;
+            for (int64_t i = 0; i < n; i++) {
+                if (o_out) o_out[i] = ho[i];
+                if (new_inf_out) new_inf_out[i] = hn[i];
+                if (r_out) r_out[i] = hr[i];
+            }
+        } else {
+            std::vector<int32_t> h((size_t)n);
+            if (o_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.o_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, o_out); }
+            if (new_inf_out) { HIPCHECK(hipMemcpyAsync(h.data(), A.newinf_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream)); HIPCHECK(hipStreamSynchronize(c->stream)); widen(h, n, new_inf_out); }
+            if (r_out) HIPCHECK(hipMemcpyAsync(r_out, A.r_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            rc = fetch_flags(c, b->scal, flags, true);
+            if (rc) return rc;
+            HIPCHECK(hipStreamSynchronize(c->stream));
+        }
+        b->cur ^= 1; b->has_anc = false;
+        return EPI_OK;
+    });
 }
 
 int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_particle,
                       const int64_t* sympt, const int64_t* pos, const double* gam,
                       int64_t* new_inf_out, int64_t* pos_out, uint32_t* flags)
 {
-    int rc = belief_check(b, "epi_step_injected");
-    if (rc) return rc;
-    if (!c || b->ctx != c || !a || !sympt || !pos || !gam) return fail(EPI_EINVAL, "epi_step_injected: NULL argument");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_injected: a phased update is in progress");
-    HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = b->n;
-    const int H = c->P.H;
-    // particle-major host arrays -> one row per age bin
-    std::vector<int32_t> hs((size_t)n * H), hp((size_t)n * H);
-    std::vector<double> hg((size_t)n * H);
-    const int64_t lim = (1LL << 31) - 1;
-    for (int64_t p = 0; p < n; p++)
-        for (int i = 0; i < H; i++) {
-            int64_t s = sympt[p * H + i], q = pos[p * H + i];
-            if (s < 0 || s > lim || q < 0 || q > lim) return fail(EPI_ERANGE, "epi_step_injected: variate out of int32 range at particle %lld", (long long)p);
-            hs[(size_t)i * (size_t)n + (size_t)p] = (int32_t)s;
-            hp[(size_t)i * (size_t)n + (size_t)p] = (int32_t)q;
-            hg[(size_t)i * (size_t)n + (size_t)p] = gam[p * H + i];
-        }
-    DevBuf ds, dp, dg, da, dni, dpo;
-    size_t cnt = (size_t)n * (size_t)H;
-    if (ds.alloc(4 * cnt) != hipSuccess || dp.alloc(4 * cnt) != hipSuccess || dg.alloc(8 * cnt) != hipSuccess ||
-        dni.alloc(4 * (size_t)n) != hipSuccess || dpo.alloc(4 * cnt) != hipSuccess)
-        return fail(EPI_ENOMEM, "epi_step_injected: hipMalloc failed");
-    HIPCHECK(hipMemcpyAsync(ds.p, hs.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(dp.p, hp.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(dg.p, hg.data(), 8 * cnt, hipMemcpyHostToDevice, c->stream));
-    StepArgs A;
-    memset(&A, 0, sizeof A);
-    A.screen = g_screen;
-    A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
-    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
-    A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
-    if (a_per_particle) {
-        if (da.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_injected: hipMalloc failed");
-        HIPCHECK(hipMemcpyAsync(da.p, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        A.a_dev = da.as<double>();
-    }
-    A.scal = b->scal; A.slot0 = (uint64_t)b->slot0;
-    A.inj_sympt = ds.as<int32_t>(); A.inj_pos = dp.as<int32_t>(); A.inj_gam = dg.as<double>();
-    A.newinf_out = dni.as<int32_t>(); A.pos_out = dpo.as<int32_t>();
-    k_step<false, MODE_INJECT><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
-    HIPCHECK(hipGetLastError());
-    if (new_inf_out) {
-        std::vector<int32_t> h((size_t)n);
-        HIPCHECK(hipMemcpyAsync(h.data(), dni.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
-        widen(h, n, new_inf_out);
-    }
-    if (pos_out) {
-        HIPCHECK(hipMemcpyAsync(hp.data(), dpo.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
+    return guarded("epi_step_injected", [&]() -> int {
+        int rc = belief_check(b, "epi_step_injected");
+        if (rc) return rc;
+        if (!c || b->ctx != c || !a || !sympt || !pos || !gam) return fail(EPI_EINVAL, "epi_step_injected: NULL argument");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_injected: a phased update is in progress");
+        HIPCHECK(hipSetDevice(c->device));
+        const int64_t n = b->n;
+        const int H = c->P.H;
+        // particle-major host arrays -> one row per age bin
+        std::vector<int32_t> hs((size_t)n * H), hp((size_t)n * H);
+        std::vector<double> hg((size_t)n * H);
+        const int64_t lim = (1LL << 31) - 1;
         for (int64_t p = 0; p < n; p++)
-            for (int i = 0; i < H; i++) pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
-    }
-    rc = fetch_flags(c, b->scal, flags, true);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    b->cur ^= 1; b->has_anc = false;
-    return EPI_OK;
+            for (int i = 0; i < H; i++) {
+                int64_t s = sympt[p * H + i], q = pos[p * H + i];
+                if (s < 0 || s > lim || q < 0 || q > lim) return fail(EPI_ERANGE, "epi_step_injected: variate out of int32 range at particle %lld", (long long)p);
+                hs[(size_t)i * (size_t)n + (size_t)p] = (int32_t)s;
+                hp[(size_t)i * (size_t)n + (size_t)p] = (int32_t)q;
+                hg[(size_t)i * (size_t)n + (size_t)p] = gam[p * H + i];
+            }
+        DevBuf ds, dp, dg, da, dni, dpo;
+        size_t cnt = (size_t)n * (size_t)H;
+        if (ds.alloc(4 * cnt) != hipSuccess || dp.alloc(4 * cnt) != hipSuccess || dg.alloc(8 * cnt) != hipSuccess ||
+            dni.alloc(4 * (size_t)n) != hipSuccess || dpo.alloc(4 * cnt) != hipSuccess)
+            return fail(EPI_ENOMEM, "epi_step_injected: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(ds.p, hs.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(dp.p, hp.data(), 4 * cnt, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(dg.p, hg.data(), 8 * cnt, hipMemcpyHostToDevice, c->stream));
+        StepArgs A;
+        memset(&A, 0, sizeof A);
+        A.screen = g_screen;
+        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+        A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
+        if (a_per_particle) {
+            if (da.alloc(sizeof(double) * (size_t)n) != hipSuccess) return fail(EPI_ENOMEM, "epi_step_injected: hipMalloc failed");
+            HIPCHECK(hipMemcpyAsync(da.p, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            A.a_dev = da.as<double>();
+        }
+        A.scal = b->scal; A.slot0 = (uint64_t)b->slot0;
+        A.inj_sympt = ds.as<int32_t>(); A.inj_pos = dp.as<int32_t>(); A.inj_gam = dg.as<double>();
+        A.newinf_out = dni.as<int32_t>(); A.pos_out = dpo.as<int32_t>();
+        k_step<false, MODE_INJECT><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        HIPCHECK(hipGetLastError());
+        if (new_inf_out) {
+            std::vector<int32_t> h((size_t)n);
+            HIPCHECK(hipMemcpyAsync(h.data(), dni.p, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            widen(h, n, new_inf_out);
+        }
+        if (pos_out) {
+            HIPCHECK(hipMemcpyAsync(hp.data(), dpo.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            for (int64_t p = 0; p < n; p++)
+                for (int i = 0; i < H; i++) pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
+        }
+        rc = fetch_flags(c, b->scal, flags, true);
+        if (rc) return rc;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        b->cur ^= 1; b->has_anc = false;
+        return EPI_OK;
+    });
 }
 
 int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32_t step,
                       int64_t* sympt_out, int64_t* pos_out, double* gam_out, uint32_t* flags)
 {
-    int rc = belief_check(b, "epi_step_variates");
-    if (rc) return rc;
-    if (!c || b->ctx != c || !sympt_out || !pos_out || !gam_out) return fail(EPI_EINVAL, "epi_step_variates: NULL argument");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_variates: a phased update is in progress");
-    HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = b->n;
-    const int H = c->P.H;
-    const size_t cnt = (size_t)n * (size_t)H;
-    DevBuf ds, dp, dg;
-    if (ds.alloc(4 * cnt) != hipSuccess || dp.alloc(4 * cnt) != hipSuccess || dg.alloc(8 * cnt) != hipSuccess)
-        return fail(EPI_ENOMEM, "epi_step_variates: hipMalloc failed");
-    StepArgs A;
-    memset(&A, 0, sizeof A);
-    A.screen = g_screen;
-    A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
-    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
-    A.a = a; A.a_row_stride = 1;
-    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
-    A.rec_sympt = ds.as<int32_t>(); A.rec_pos = dp.as<int32_t>(); A.rec_gam = dg.as<double>();
-    k_step<false, MODE_RECORD><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
-    HIPCHECK(hipGetLastError());
-    std::vector<int32_t> hs(cnt), hp(cnt);
-    std::vector<double> hg(cnt);
-    HIPCHECK(hipMemcpyAsync(hs.data(), ds.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipMemcpyAsync(hp.data(), dp.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipMemcpyAsync(hg.data(), dg.p, 8 * cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    for (int64_t p = 0; p < n; p++)
-        for (int i = 0; i < H; i++) {
-            sympt_out[p * H + i] = hs[(size_t)i * (size_t)n + (size_t)p];
-            pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
-            gam_out[p * H + i] = hg[(size_t)i * (size_t)n + (size_t)p];
-        }
-    rc = fetch_flags(c, b->scal, flags, true);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    b->cur ^= 1; b->has_anc = false;
-    return EPI_OK;
+    return guarded("epi_step_variates", [&]() -> int {
+        int rc = belief_check(b, "epi_step_variates");
+        if (rc) return rc;
+        if (!c || b->ctx != c || !sympt_out || !pos_out || !gam_out) return fail(EPI_EINVAL, "epi_step_variates: NULL argument");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_step_variates: a phased update is in progress");
+        HIPCHECK(hipSetDevice(c->device));
+        const int64_t n = b->n;
+        const int H = c->P.H;
+        const size_t cnt = (size_t)n * (size_t)H;
+        DevBuf ds, dp, dg;
+        if (ds.alloc(4 * cnt) != hipSuccess || dp.alloc(4 * cnt) != hipSuccess || dg.alloc(8 * cnt) != hipSuccess)
+            return fail(EPI_ENOMEM, "epi_step_variates: hipMalloc failed");
+        StepArgs A;
+        memset(&A, 0, sizeof A);
+        A.screen = g_screen;
+        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+        A.a = a; A.a_row_stride = 1;
+        A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
+        A.rec_sympt = ds.as<int32_t>(); A.rec_pos = dp.as<int32_t>(); A.rec_gam = dg.as<double>();
+        k_step<false, MODE_RECORD><<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(A, c->d_params);
+        HIPCHECK(hipGetLastError());
+        std::vector<int32_t> hs(cnt), hp(cnt);
+        std::vector<double> hg(cnt);
+        HIPCHECK(hipMemcpyAsync(hs.data(), ds.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipMemcpyAsync(hp.data(), dp.p, 4 * cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipMemcpyAsync(hg.data(), dg.p, 8 * cnt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t p = 0; p < n; p++)
+            for (int i = 0; i < H; i++) {
+                sympt_out[p * H + i] = hs[(size_t)i * (size_t)n + (size_t)p];
+                pos_out[p * H + i] = hp[(size_t)i * (size_t)n + (size_t)p];
+                gam_out[p * H + i] = hg[(size_t)i * (size_t)n + (size_t)p];
+            }
+        rc = fetch_flags(c, b->scal, flags, true);
+        if (rc) return rc;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        b->cur ^= 1; b->has_anc = false;
+        return EPI_OK;
+    });
 }
 
 int epi_sample_binomial(epi_ctx* c, int64_t count, const int64_t* n, const double* p, uint64_t seed, uint32_t step,
                         uint32_t bin, int which, int64_t* out)
 {
-    if (!c || !n || !p || !out || count < 1 || bin > 0xffffu) return fail(EPI_EINVAL, "epi_sample_binomial: bad argument");
-    HIPCHECK(hipSetDevice(c->device));
-    std::vector<int32_t> hn((size_t)count);
-    for (int64_t j = 0; j < count; j++) {
-        if (n[j] >= (1LL << 31) || n[j] <= -(1LL << 31)) return fail(EPI_ERANGE, "epi_sample_binomial: n[%lld] out of int32 range", (long long)j);
-        hn[(size_t)j] = (int32_t)n[j];
-    }
-    DevBuf dn, dp, dout;
-    if (dn.alloc(4 * (size_t)count) != hipSuccess || dp.alloc(8 * (size_t)count) != hipSuccess || dout.alloc(4 * (size_t)count) != hipSuccess)
-        return fail(EPI_ENOMEM, "epi_sample_binomial: hipMalloc failed");
-    HIPCHECK(hipMemcpyAsync(dn.p, hn.data(), 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(dp.p, p, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>(), g_screen != 0, LfTable{c->d_lf, LF_TABLE_N});
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(hn.data(), dout.p, 4 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    for (int64_t j = 0; j < count; j++) out[j] = hn[(size_t)j];
-    return EPI_OK;
+    return guarded("epi_sample_binomial", [&]() -> int {
+        if (!c || !n || !p || !out || count < 1 || bin > 0xffffu) return fail(EPI_EINVAL, "epi_sample_binomial: bad argument");
+        HIPCHECK(hipSetDevice(c->device));
+        std::vector<int32_t> hn((size_t)count);
+        for (int64_t j = 0; j < count; j++) {
+            if (n[j] >= (1LL << 31) || n[j] <= -(1LL << 31)) return fail(EPI_ERANGE, "epi_sample_binomial: n[%lld] out of int32 range", (long long)j);
+            hn[(size_t)j] = (int32_t)n[j];
+        }
+        DevBuf dn, dp, dout;
+        if (dn.alloc(4 * (size_t)count) != hipSuccess || dp.alloc(8 * (size_t)count) != hipSuccess || dout.alloc(4 * (size_t)count) != hipSuccess)
+            return fail(EPI_ENOMEM, "epi_sample_binomial: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(dn.p, hn.data(), 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(dp.p, p, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+        k_sample_binomial<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dn.as<int32_t>(), dp.as<double>(), seed, step, bin, which, dout.as<int32_t>(), g_screen != 0, LfTable{c->d_lf, LF_TABLE_N});
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(hn.data(), dout.p, 4 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t j = 0; j < count; j++) out[j] = hn[(size_t)j];
+        return EPI_OK;
+    });
 }
 
 int epi_sample_gamma(epi_ctx* c, int64_t count, const double* shape, const double* scale, uint64_t seed, uint32_t step,
                      uint32_t bin, double* out)
 {
-    if (!c || !shape || !scale || !out || count < 1 || bin > 0xffffu) return fail(EPI_EINVAL, "epi_sample_gamma: bad argument");
-    HIPCHECK(hipSetDevice(c->device));
-    DevBuf dk, ds, dout;
-    if (dk.alloc(8 * (size_t)count) != hipSuccess || ds.alloc(8 * (size_t)count) != hipSuccess || dout.alloc(8 * (size_t)count) != hipSuccess)
-        return fail(EPI_ENOMEM, "epi_sample_gamma: hipMalloc failed");
-    HIPCHECK(hipMemcpyAsync(dk.p, shape, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(hipMemcpyAsync(ds.p, scale, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>(), g_screen != 0);
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(out, dout.p, 8 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    return EPI_OK;
+    return guarded("epi_sample_gamma", [&]() -> int {
+        if (!c || !shape || !scale || !out || count < 1 || bin > 0xffffu) return fail(EPI_EINVAL, "epi_sample_gamma: bad argument");
+        HIPCHECK(hipSetDevice(c->device));
+        DevBuf dk, ds, dout;
+        if (dk.alloc(8 * (size_t)count) != hipSuccess || ds.alloc(8 * (size_t)count) != hipSuccess || dout.alloc(8 * (size_t)count) != hipSuccess)
+            return fail(EPI_ENOMEM, "epi_sample_gamma: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(dk.p, shape, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(hipMemcpyAsync(ds.p, scale, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+        k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>(), g_screen != 0);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(out, dout.p, 8 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        return EPI_OK;
+    });
 }
 
 int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, int act_per_particle, int act_per_day, double a_prev0,
                       uint64_t seed, uint32_t step0, int64_t* hist, double* rew, uint32_t* flags)
 {
-    int rc = belief_check(b, "epi_rollout_batch");
-    if (rc) return rc;
-    if (!c || b->ctx != c || !actions || T < 1) return fail(EPI_EINVAL, "epi_rollout_batch: bad argument");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_rollout_batch: a phased update is in progress");
-    HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = b->n;
-    const int64_t arow = act_per_day ? T : 1;
-    const size_t acount = (size_t)(act_per_particle ? n : 1) * (size_t)arow;
-    DevBuf dact, dhist, drew;
-    if (dact.alloc(sizeof(double) * acount) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed");
-    HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * acount, hipMemcpyHostToDevice, c->stream));
-    if (hist && dhist.alloc(sizeof(int32_t) * 4 * (size_t)n * (size_t)T) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed (history)");
-    if (rew && drew.alloc(sizeof(double) * (size_t)n * (size_t)T) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed (rewards)");
-    for (int t = 0; t < T; t++) {
-        StepArgs A;
-        memset(&A, 0, sizeof A);
-    A.screen = g_screen;
-        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
-        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
-        const int64_t tcol = act_per_day ? t : 0;
-        const int64_t pcol = act_per_day ? t - 1 : 0;          // column of the previous day's action
-        A.a_row_stride = 1;
-        if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
-        else A.a = actions[tcol];
-        if (t == 0) A.a_prev = a_prev0;                         // prev_action of the start state (typedef.jl:180,216)
-        else if (act_per_particle) { A.a_prev_dev = dact.as<double>(); A.a_prev_col = pcol; }
-        else A.a_prev = actions[pcol];
-        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
-        if (hist) A.hist = dhist.as<int32_t>() + (size_t)t * 4 * (size_t)n;
-        if (rew) A.r_out = drew.as<double>() + (size_t)t * (size_t)n;
-        HIPCHECK(launch_step<false>(c, A));
-        b->cur ^= 1; b->has_anc = false;
-    }
-    if (hist) {
-        std::vector<int32_t> h((size_t)4 * (size_t)n * (size_t)T);
-        HIPCHECK(hipMemcpyAsync(h.data(), dhist.p, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    return guarded("epi_rollout_batch", [&]() -> int {
+        int rc = belief_check(b, "epi_rollout_batch");
+        if (rc) return rc;
+        if (!c || b->ctx != c || !actions || T < 1) return fail(EPI_EINVAL, "epi_rollout_batch: bad argument");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_rollout_batch: a phased update is in progress");
+        HIPCHECK(hipSetDevice(c->device));
+        const int64_t n = b->n;
+        const int64_t arow = act_per_day ? T : 1;
+        const size_t acount = (size_t)(act_per_particle ? n : 1) * (size_t)arow;
+        DevBuf dact, dhist, drew;
+        if (dact.alloc(sizeof(double) * acount) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * acount, hipMemcpyHostToDevice, c->stream));
+        if (hist && dhist.alloc(sizeof(int32_t) * 4 * (size_t)n * (size_t)T) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed (history)");
+        if (rew && drew.alloc(sizeof(double) * (size_t)n * (size_t)T) != hipSuccess) return fail(EPI_ENOMEM, "epi_rollout_batch: hipMalloc failed (rewards)");
+        for (int t = 0; t < T; t++) {
+            StepArgs A;
+            memset(&A, 0, sizeof A);
+        A.screen = g_screen;
+            A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+            A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+            const int64_t tcol = act_per_day ? t : 0;
+            const int64_t pcol = act_per_day ? t - 1 : 0;          // column of the previous day's action
+            A.a_row_stride = 1;
+            if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
+            else A.a = actions[tcol];
+            if (t == 0) A.a_prev = a_prev0;                         // prev_action of the start state (typedef.jl:180,216)
+            else if (act_per_particle) { A.a_prev_dev = dact.as<double>(); A.a_prev_col = pcol; }
+            else A.a_prev = actions[pcol];
+            A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
+            if (hist) A.hist = dhist.as<int32_t>() + (size_t)t * 4 * (size_t)n;
+            if (rew) A.r_out = drew.as<double>() + (size_t)t * (size_t)n;
+            HIPCHECK(launch_step<false>(c, A));
+            b->cur ^= 1; b->has_anc = false;
+        }
+        if (hist) {
+            std::vector<int32_t> h((size_t)4 * (size_t)n * (size_t)T);
+            HIPCHECK(hipMemcpyAsync(h.data(), dhist.p, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            for (int64_t p = 0; p < n; p++)
+                for (int t = 0; t < T; t++)
+                    for (int k = 0; k < 4; k++) hist[(p * T + t) * 4 + k] = h[((size_t)t * 4 + (size_t)k) * (size_t)n + (size_t)p];
+        }
+        if (rew) {
+            std::vector<double> h((size_t)n * (size_t)T);
+            HIPCHECK(hipMemcpyAsync(h.data(), drew.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            for (int64_t p = 0; p < n; p++)
+                for (int t = 0; t < T; t++) rew[p * T + t] = h[(size_t)t * (size_t)n + (size_t)p];
+        }
+        rc = fetch_flags(c, b->scal, flags, true);
+        if (rc) return rc;
         HIPCHECK(hipStreamSynchronize(c->stream));
-        for (int64_t p = 0; p < n; p++)
-            for (int t = 0; t < T; t++)
-                for (int k = 0; k < 4; k++) hist[(p * T + t) * 4 + k] = h[((size_t)t * 4 + (size_t)k) * (size_t)n + (size_t)p];
-    }
-    if (rew) {
-        std::vector<double> h((size_t)n * (size_t)T);
-        HIPCHECK(hipMemcpyAsync(h.data(), drew.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
-        for (int64_t p = 0; p < n; p++)
-            for (int t = 0; t < T; t++) rew[p * T + t] = h[(size_t)t * (size_t)n + (size_t)p];
-    }
-    rc = fetch_flags(c, b->scal, flags, true);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    return EPI_OK;
+        return EPI_OK;
+    });
 }
 
 int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts_per_seq, int T, const double* actions, double a_prev0,
                       double discount, uint64_t seed, uint32_t step0, double* score, uint32_t* flags)
 {
-    int rc = belief_check(start, "epi_rollout_score");
-    if (rc) return rc;
-    if (!c || start->ctx != c || !actions || !score || T < 1 || n_seq < 1 || rollouts_per_seq < 1)
-        return fail(EPI_EINVAL, "epi_rollout_score: bad argument");
-    if (start->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_rollout_score: a phased update is in progress");
-    const int64_t n = n_seq * (int64_t)rollouts_per_seq;
-    if (n >= (1LL << 31)) return fail(EPI_ERANGE, "epi_rollout_score: n_seq * rollouts_per_seq must be < 2^31");
-    HIPCHECK(hipSetDevice(c->device));
-    const int rows = start->rows;
-    const int64_t stride = ceil_div(n, 64) * 64;
-    DevBuf dact, dst[2], drew, dacc, dscore;
-    const size_t sbytes = sizeof(int32_t) * (size_t)rows * (size_t)stride;
-    if (dact.alloc(sizeof(double) * (size_t)n_seq * (size_t)T) != hipSuccess || dst[0].alloc(sbytes) != hipSuccess || dst[1].alloc(sbytes) != hipSuccess ||
-        drew.alloc(sizeof(double) * (size_t)n) != hipSuccess || dacc.alloc(sizeof(double) * (size_t)n) != hipSuccess ||
-        dscore.alloc(sizeof(double) * (size_t)n_seq) != hipSuccess)
-        return fail(EPI_ENOMEM, "epi_rollout_score: hipMalloc failed");
-    HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * (size_t)n_seq * (size_t)T, hipMemcpyHostToDevice, c->stream));
-    const dim3 grid((unsigned)ceil_div(n, TPB)), blk(TPB);
-    k_replicate<<<grid, blk, 0, c->stream>>>(n, start->buf[start->cur], start->stride, start->has_anc ? start->anc : nullptr, start->n,
-                                             dst[0].as<int32_t>(), stride, rows);
-    HIPCHECK(hipGetLastError());
-    double scale = 1.0;
-    for (int t = 0; t < T; t++) {
-        StepArgs A;
-        memset(&A, 0, sizeof A);
-        A.screen = g_screen;
-        A.n = n; A.in = dst[t & 1].as<int32_t>(); A.in_stride = stride;
-        A.out = dst[(t & 1) ^ 1].as<int32_t>(); A.out_stride = stride;
-        A.a_dev = dact.as<double>(); A.a_row_stride = T; A.a_col = t; A.a_div = rollouts_per_seq;
-        if (t == 0) A.a_prev = a_prev0;
-        else { A.a_prev_dev = dact.as<double>(); A.a_prev_col = t - 1; }
-        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = 0; A.scal = start->scal;
-        A.r_out = drew.as<double>();
-        HIPCHECK(launch_step<false>(c, A));
-        k_score_acc<<<grid, blk, 0, c->stream>>>(n, dacc.as<double>(), drew.as<double>(), scale, t == 0);
-        scale *= discount;
-    }
-    k_score_mean<<<dim3((unsigned)ceil_div(n_seq, TPB)), blk, 0, c->stream>>>(n_seq, rollouts_per_seq, dacc.as<double>(), dscore.as<double>());
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(score, dscore.p, sizeof(double) * (size_t)n_seq, hipMemcpyDeviceToHost, c->stream));
-    rc = fetch_flags(c, start->scal, flags, true);
-    if (rc) return rc;
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    return EPI_OK;
+    return guarded("epi_rollout_score", [&]() -> int {
+        int rc = belief_check(start, "epi_rollout_score");
+        if (rc) return rc;
+        if (!c || start->ctx != c || !actions || !score || T < 1 || n_seq < 1 || rollouts_per_seq < 1)
+            return fail(EPI_EINVAL, "epi_rollout_score: bad argument");
+        if (start->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_rollout_score: a phased update is in progress");
+        const int64_t n = n_seq * (int64_t)rollouts_per_seq;
+        if (n >= (1LL << 31)) return fail(EPI_ERANGE, "epi_rollout_score: n_seq * rollouts_per_seq must be < 2^31");
+        HIPCHECK(hipSetDevice(c->device));
+        const int rows = start->rows;
+        const int64_t stride = ceil_div(n, 64) * 64;
+        DevBuf dact, dst[2], drew, dacc, dscore;
+        const size_t sbytes = sizeof(int32_t) * (size_t)rows * (size_t)stride;
+        if (dact.alloc(sizeof(double) * (size_t)n_seq * (size_t)T) != hipSuccess || dst[0].alloc(sbytes) != hipSuccess || dst[1].alloc(sbytes) != hipSuccess ||
+            drew.alloc(sizeof(double) * (size_t)n) != hipSuccess || dacc.alloc(sizeof(double) * (size_t)n) != hipSuccess ||
+            dscore.alloc(sizeof(double) * (size_t)n_seq) != hipSuccess)
+            return fail(EPI_ENOMEM, "epi_rollout_score: hipMalloc failed");
+        HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * (size_t)n_seq * (size_t)T, hipMemcpyHostToDevice, c->stream));
+        const dim3 grid((unsigned)ceil_div(n, TPB)), blk(TPB);
+        k_replicate<<<grid, blk, 0, c->stream>>>(n, start->buf[start->cur], start->stride, start->has_anc ? start->anc : nullptr, start->n,
+                                                 dst[0].as<int32_t>(), stride, rows);
+        HIPCHECK(hipGetLastError());
+        double scale = 1.0;
+        for (int t = 0; t < T; t++) {
+            StepArgs A;
+            memset(&A, 0, sizeof A);
+            A.screen = g_screen;
+            A.n = n; A.in = dst[t & 1].as<int32_t>(); A.in_stride = stride;
+            A.out = dst[(t & 1) ^ 1].as<int32_t>(); A.out_stride = stride;
+            A.a_dev = dact.as<double>(); A.a_row_stride = T; A.a_col = t; A.a_div = rollouts_per_seq;
+            if (t == 0) A.a_prev = a_prev0;
+            else { A.a_prev_dev = dact.as<double>(); A.a_prev_col = t - 1; }
+            A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = 0; A.scal = start->scal;
+            A.r_out = drew.as<double>();
+            HIPCHECK(launch_step<false>(c, A));
+            k_score_acc<<<grid, blk, 0, c->stream>>>(n, dacc.as<double>(), drew.as<double>(), scale, t == 0);
+            scale *= discount;
+        }
+        k_score_mean<<<dim3((unsigned)ceil_div(n_seq, TPB)), blk, 0, c->stream>>>(n_seq, rollouts_per_seq, dacc.as<double>(), dscore.as<double>());
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(score, dscore.p, sizeof(double) * (size_t)n_seq, hipMemcpyDeviceToHost, c->stream));
+        rc = fetch_flags(c, start->scal, flags, true);
+        if (rc) return rc;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        return EPI_OK;
+    });
 }
 
 // ---- ensembles kept on the device (ODE fitting) ------------------------------------
@@ -2074,50 +2112,57 @@ int epi_ensemble_destroy(epi_ensemble* e)
 int epi_ensemble_simulate(epi_ctx* c, epi_belief* b, int T, const double* actions, int act_per_particle, int act_per_day, double a_prev0,
                           uint64_t seed, uint32_t step0, epi_ensemble** out, uint32_t* flags)
 {
-    int rc = belief_check(b, "epi_ensemble_simulate");
-    if (rc) return rc;
-    if (!c || b->ctx != c || !actions || !out || T < 1) return fail(EPI_EINVAL, "epi_ensemble_simulate: bad argument");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_ensemble_simulate: a phased update is in progress");
-    HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = b->n;
-    const int64_t arow = act_per_day ? T : 1;
-    const size_t acount = (size_t)(act_per_particle ? n : 1) * (size_t)arow;
-    epi_ensemble* e = new epi_ensemble();
-    e->ctx = c; e->n = n; e->T = T;
-    DevBuf dact;
-    hipError_t he = dact.alloc(sizeof(double) * acount);
-    if (he == hipSuccess) he = hipMalloc((void**)&e->hist, sizeof(int32_t) * 4 * (size_t)n * (size_t)T);
-    if (he == hipSuccess) he = hipMalloc((void**)&e->act, sizeof(double) * (size_t)n);
-    if (he == hipSuccess) he = hipMalloc((void**)&e->partial, sizeof(double) * ((size_t)ceil_div(n, TPB) + 1));
-    if (he != hipSuccess) { epi_ensemble_destroy(e); return fail(EPI_ENOMEM, "epi_ensemble_simulate: hipMalloc failed: %s", hipGetErrorString(he)); }
-    HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * acount, hipMemcpyHostToDevice, c->stream));
-    {   // the action the controlled ODE models see: the trajectory's first-day action
-        std::vector<double> a0((size_t)n);
-        for (int64_t m = 0; m < n; m++) a0[(size_t)m] = actions[act_per_particle ? (size_t)m * (size_t)arow : 0];
-        HIPCHECK(hipMemcpyAsync(e->act, a0.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    return guarded("epi_ensemble_simulate", [&]() -> int {
+        int rc = belief_check(b, "epi_ensemble_simulate");
+        if (rc) return rc;
+        if (!c || b->ctx != c || !actions || !out || T < 1) return fail(EPI_EINVAL, "epi_ensemble_simulate: bad argument");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_ensemble_simulate: a phased update is in progress");
+        HIPCHECK(hipSetDevice(c->device));
+        const int64_t n = b->n;
+        const int64_t arow = act_per_day ? T : 1;
+        const size_t acount = (size_t)(act_per_particle ? n : 1) * (size_t)arow;
+        epi_ensemble* e = new epi_ensemble();
+        e->ctx = c; e->n = n; e->T = T;
+        struct Owner {            // frees the half-built ensemble on every early return
+            epi_ensemble* e;
+            ~Owner() { if (e) epi_ensemble_destroy(e); }
+        } owner{e};
+        DevBuf dact;
+        hipError_t he = dact.alloc(sizeof(double) * acount);
+        if (he == hipSuccess) he = hipMalloc((void**)&e->hist, sizeof(int32_t) * 4 * (size_t)n * (size_t)T);
+        if (he == hipSuccess) he = hipMalloc((void**)&e->act, sizeof(double) * (size_t)n);
+        if (he == hipSuccess) he = hipMalloc((void**)&e->partial, sizeof(double) * ((size_t)ceil_div(n, TPB) + 1));
+        if (he != hipSuccess) return fail(EPI_ENOMEM, "epi_ensemble_simulate: hipMalloc failed: %s", hipGetErrorString(he));
+        HIPCHECK(hipMemcpyAsync(dact.p, actions, sizeof(double) * acount, hipMemcpyHostToDevice, c->stream));
+        {   // the action the controlled ODE models see: the trajectory's first-day action
+            std::vector<double> a0((size_t)n);
+            for (int64_t m = 0; m < n; m++) a0[(size_t)m] = actions[act_per_particle ? (size_t)m * (size_t)arow : 0];
+            HIPCHECK(hipMemcpyAsync(e->act, a0.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+        }
+        for (int t = 0; t < T; t++) {
+            StepArgs A;
+            memset(&A, 0, sizeof A);
+            A.screen = g_screen;
+            A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
+            A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+            const int64_t tcol = act_per_day ? t : 0;
+            A.a_row_stride = 1;
+            if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
+            else A.a = actions[tcol];
+            A.a_prev = a_prev0;                                   // rewards are not computed here
+            A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
+            A.hist = e->hist + (size_t)t * 4 * (size_t)n;
+            HIPCHECK(launch_step<false>(c, A));
+            b->cur ^= 1; b->has_anc = false;
+        }
+        rc = fetch_flags(c, b->scal, flags, true);
+        if (rc) return rc;
         HIPCHECK(hipStreamSynchronize(c->stream));
-    }
-    for (int t = 0; t < T; t++) {
-        StepArgs A;
-        memset(&A, 0, sizeof A);
-        A.screen = g_screen;
-        A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
-        A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
-        const int64_t tcol = act_per_day ? t : 0;
-        A.a_row_stride = 1;
-        if (act_per_particle) { A.a_dev = dact.as<double>(); A.a_row_stride = arow; A.a_col = tcol; }
-        else A.a = actions[tcol];
-        A.a_prev = a_prev0;                                   // rewards are not computed here
-        A.seed = seed; A.step = step0 + (uint32_t)t; A.slot0 = (uint64_t)b->slot0; A.scal = b->scal;
-        A.hist = e->hist + (size_t)t * 4 * (size_t)n;
-        HIPCHECK(launch_step<false>(c, A));
-        b->cur ^= 1; b->has_anc = false;
-    }
-    rc = fetch_flags(c, b->scal, flags, true);
-    if (rc) { epi_ensemble_destroy(e); return rc; }
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    *out = e;
-    return EPI_OK;
+        owner.e = nullptr;
+        *out = e;
+        return EPI_OK;
+    });
 }
 
 int epi_ensemble_shape(const epi_ensemble* e, int64_t* n, int* T)
@@ -2130,43 +2175,47 @@ int epi_ensemble_shape(const epi_ensemble* e, int64_t* n, int* T)
 
 int epi_ensemble_download(epi_ensemble* e, int64_t* hist)
 {
-    if (!e || !hist) return fail(EPI_EINVAL, "epi_ensemble_download: NULL argument");
-    epi_ctx* c = e->ctx;
-    HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = e->n;
-    const int T = e->T;
-    std::vector<int32_t> h((size_t)4 * (size_t)n * (size_t)T);
-    HIPCHECK(hipMemcpyAsync(h.data(), e->hist, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    for (int64_t p = 0; p < n; p++)
-        for (int t = 0; t < T; t++)
-            for (int k = 0; k < 3; k++) hist[(p * T + t) * 3 + k] = h[((size_t)t * 4 + (size_t)k) * (size_t)n + (size_t)p];
-    return EPI_OK;
+    return guarded("epi_ensemble_download", [&]() -> int {
+        if (!e || !hist) return fail(EPI_EINVAL, "epi_ensemble_download: NULL argument");
+        epi_ctx* c = e->ctx;
+        HIPCHECK(hipSetDevice(c->device));
+        const int64_t n = e->n;
+        const int T = e->T;
+        std::vector<int32_t> h((size_t)4 * (size_t)n * (size_t)T);
+        HIPCHECK(hipMemcpyAsync(h.data(), e->hist, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t p = 0; p < n; p++)
+            for (int t = 0; t < T; t++)
+                for (int k = 0; k < 3; k++) hist[(p * T + t) * 3 + k] = h[((size_t)t * 4 + (size_t)k) * (size_t)n + (size_t)p];
+        return EPI_OK;
+    });
 }
 
 int epi_ensemble_loss(epi_ctx* c, epi_ensemble* e, int kind, const double* p, int n_p, int substeps, double* loss, double* per_traj)
 {
-    if (!c || !e || e->ctx != c || !p || !loss) return fail(EPI_EINVAL, "epi_ensemble_loss: bad argument");
-    static const int want[4] = {2, 3, 3, 5};              // parameters of SIR, SIR_CTRL, SEIR, SEIR_CTRL (src/ODEFit.jl:40-55)
-    if (kind < 0 || kind > 3) return fail(EPI_EINVAL, "epi_ensemble_loss: kind = %d", kind);
-    if (n_p != want[kind]) return fail(EPI_EINVAL, "epi_ensemble_loss: model %d takes %d parameters, got %d", kind, want[kind], n_p);
-    if (substeps < 1 || substeps > 4096) return fail(EPI_EINVAL, "epi_ensemble_loss: substeps = %d", substeps);
-    HIPCHECK(hipSetDevice(c->device));
-    double q[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < n_p; i++) q[i] = p[i];
-    DevBuf dper;
-    if (per_traj && dper.alloc(sizeof(double) * (size_t)e->n) != hipSuccess) return fail(EPI_ENOMEM, "epi_ensemble_loss: hipMalloc failed");
-    const int64_t nb = ceil_div(e->n, TPB);
-    k_ode_loss<<<dim3((unsigned)nb), dim3(TPB), 0, c->stream>>>(e->n, e->T, e->hist, e->act, kind, q[0], q[1], q[2], q[3], q[4], substeps,
-                                                              (double)c->P.N, per_traj ? dper.as<double>() : nullptr, e->partial);
-    k_sum_partials<<<1, 1024, 0, c->stream>>>(nb, e->partial, e->partial + nb);
-    HIPCHECK(hipGetLastError());
-    double total = 0.0;
-    HIPCHECK(hipMemcpyAsync(&total, e->partial + nb, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (per_traj) HIPCHECK(hipMemcpyAsync(per_traj, dper.p, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    *loss = total / (double)e->n;                           // scaled by the number of simulations (src/ODEFit.jl:289)
-    return EPI_OK;
+    return guarded("epi_ensemble_loss", [&]() -> int {
+        if (!c || !e || e->ctx != c || !p || !loss) return fail(EPI_EINVAL, "epi_ensemble_loss: bad argument");
+        static const int want[4] = {2, 3, 3, 5};              // parameters of SIR, SIR_CTRL, SEIR, SEIR_CTRL (src/ODEFit.jl:40-55)
+        if (kind < 0 || kind > 3) return fail(EPI_EINVAL, "epi_ensemble_loss: kind = %d", kind);
+        if (n_p != want[kind]) return fail(EPI_EINVAL, "epi_ensemble_loss: model %d takes %d parameters, got %d", kind, want[kind], n_p);
+        if (substeps < 1 || substeps > 4096) return fail(EPI_EINVAL, "epi_ensemble_loss: substeps = %d", substeps);
+        HIPCHECK(hipSetDevice(c->device));
+        double q[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < n_p; i++) q[i] = p[i];
+        DevBuf dper;
+        if (per_traj && dper.alloc(sizeof(double) * (size_t)e->n) != hipSuccess) return fail(EPI_ENOMEM, "epi_ensemble_loss: hipMalloc failed");
+        const int64_t nb = ceil_div(e->n, TPB);
+        k_ode_loss<<<dim3((unsigned)nb), dim3(TPB), 0, c->stream>>>(e->n, e->T, e->hist, e->act, kind, q[0], q[1], q[2], q[3], q[4], substeps,
+                                                                  (double)c->P.N, per_traj ? dper.as<double>() : nullptr, e->partial);
+        k_sum_partials<<<1, 1024, 0, c->stream>>>(nb, e->partial, e->partial + nb);
+        HIPCHECK(hipGetLastError());
+        double total = 0.0;
+        HIPCHECK(hipMemcpyAsync(&total, e->partial + nb, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        if (per_traj) HIPCHECK(hipMemcpyAsync(per_traj, dper.p, sizeof(double) * (size_t)e->n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        *loss = total / (double)e->n;                           // scaled by the number of simulations (src/ODEFit.jl:289)
+        return EPI_OK;
+    });
 }
 
 // ---- the filter update ---------------------------------------------------------
@@ -2271,10 +2320,12 @@ static int enqueue_update(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, do
 
 int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step)
 {
-    int rc = update_checks(c, b, "epi_pf_update");
-    if (rc) return rc;
-    HIPCHECK(hipSetDevice(c->device));
-    return enqueue_update(c, b, own_scratch(b), a, o, seed, step);
+    return guarded("epi_pf_update_async", [&]() -> int {
+        int rc = update_checks(c, b, "epi_pf_update");
+        if (rc) return rc;
+        HIPCHECK(hipSetDevice(c->device));
+        return enqueue_update(c, b, own_scratch(b), a, o, seed, step);
+    });
 }
 
 // diagnostics of the update whose scalars are `d`; waits for the stream, clears the flags
@@ -2346,6 +2397,7 @@ int epi_pf_update_noalloc(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
     return collect_from(c, b, sc.scal, loglik, ess, flags);
 }
 
+#ifdef EPI_TESTING
 int epi_debug_step_impl(int cooperative)
 {
     g_coop = cooperative < 0 ? 0 : (cooperative > 2 ? 2 : cooperative);
@@ -2392,6 +2444,7 @@ int epi_debug_screen(int enable)
     g_screen = enable != 0;
     return EPI_OK;
 }
+#endif // EPI_TESTING
 
 int epi_ctx_timing(epi_ctx* c, int enable)
 {
@@ -2432,18 +2485,20 @@ float epi_last_predict_ms(epi_ctx* c)
 
 int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* lwmax_local)
 {
-    int rc = belief_check(b, "epi_pf_predict");
-    if (rc) return rc;
-    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_predict: belief belongs to another context");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict: previous update not finished");
-    HIPCHECK(hipSetDevice(c->device));
-    rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
-    if (rc) return rc;
-    DevScalars h;
-    if (int rs = read_scalars(c, b->scal, &h)) return rs;
-    if (lwmax_local) *lwmax_local = h.lwmax_bits ? order_decode(h.lwmax_bits) : -INFINITY;
-    b->phase = PH_PREDICTED;
-    return EPI_OK;
+    return guarded("epi_pf_predict", [&]() -> int {
+        int rc = belief_check(b, "epi_pf_predict");
+        if (rc) return rc;
+        if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_predict: belief belongs to another context");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict: previous update not finished");
+        HIPCHECK(hipSetDevice(c->device));
+        rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
+        if (rc) return rc;
+        DevScalars h;
+        if (int rs = read_scalars(c, b->scal, &h)) return rs;
+        if (lwmax_local) *lwmax_local = h.lwmax_bits ? order_decode(h.lwmax_bits) : -INFINITY;
+        b->phase = PH_PREDICTED;
+        return EPI_OK;
+    });
 }
 
 int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_local, double* sumsq_local, uint32_t* flags_local)
@@ -2467,17 +2522,19 @@ int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_loc
 
 int epi_pf_predict_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* d_lwmax_local)
 {
-    int rc = belief_check(b, "epi_pf_predict_dev");
-    if (rc) return rc;
-    if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_dev: bad argument");
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict_dev: previous update not finished");
-    HIPCHECK(hipSetDevice(c->device));
-    rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
-    if (rc) return rc;
-    k_scal_export_lwmax<<<1, 1, 0, c->stream>>>(b->scal, d_lwmax_local);
-    HIPCHECK(hipGetLastError());
-    b->phase = PH_PREDICTED;
-    return EPI_OK;
+    return guarded("epi_pf_predict_dev", [&]() -> int {
+        int rc = belief_check(b, "epi_pf_predict_dev");
+        if (rc) return rc;
+        if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_dev: bad argument");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict_dev: previous update not finished");
+        HIPCHECK(hipSetDevice(c->device));
+        rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
+        if (rc) return rc;
+        k_scal_export_lwmax<<<1, 1, 0, c->stream>>>(b->scal, d_lwmax_local);
+        HIPCHECK(hipGetLastError());
+        b->phase = PH_PREDICTED;
+        return EPI_OK;
+    });
 }
 
 int epi_pf_weigh_dev(epi_ctx* c, epi_belief* b, const double* d_lwmax_global, double* d_totals)
@@ -2716,30 +2773,32 @@ int epi_belief_suminf_quantiles(epi_ctx* c, epi_belief* b, const double* q, int 
 
 int epi_belief_sample(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
 {
-    int rc = belief_check(b, "epi_belief_sample");
-    if (rc) return rc;
-    if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_sample: a phased update is in progress");
-    HIPCHECK(hipSetDevice(c->device));
-    const int H = c->P.H, D = c->P.D, D1 = D + 1;
-    Rng g = rng_make(seed, ctr, 0);
-    uint32_t w[4];
-    rng_block(g, K_INIT, 0x300u, 0, w);
-    uint64_t r53 = (((uint64_t)(w[0] >> 5)) << 26) | (uint64_t)(w[1] >> 6);
-    int64_t slot = (int64_t)(((__int128)r53 * b->n) >> 53);
-    int32_t col = (int32_t)slot;
-    HIPCHECK(hipStreamSynchronize(c->stream));
-    if (b->has_anc) HIPCHECK(hipMemcpy(&col, b->anc + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
-    std::vector<int32_t> h((size_t)b->rows);
-    HIPCHECK(hipMemcpy2D(h.data(), sizeof(int32_t), b->buf[b->cur] + col, sizeof(int32_t) * (size_t)b->stride, sizeof(int32_t), (size_t)b->rows, hipMemcpyDeviceToHost));
-    if (S) *S = h[0];
-    if (R) *R = h[1];
-    if (I) for (int i = 0; i < H; i++) I[i] = h[(size_t)(2 + i)];
-    if (T) {
-        for (int j = 0; j < D1 * H; j++) T[j] = 0;
-        for (int cidx = 1; cidx < H; cidx++)
-            for (int r = 0; r < D; r++) T[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx)];
-    }
-    return EPI_OK;
+    return guarded("epi_belief_sample", [&]() -> int {
+        int rc = belief_check(b, "epi_belief_sample");
+        if (rc) return rc;
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_sample: a phased update is in progress");
+        HIPCHECK(hipSetDevice(c->device));
+        const int H = c->P.H, D = c->P.D, D1 = D + 1;
+        Rng g = rng_make(seed, ctr, 0);
+        uint32_t w[4];
+        rng_block(g, K_INIT, 0x300u, 0, w);
+        uint64_t r53 = (((uint64_t)(w[0] >> 5)) << 26) | (uint64_t)(w[1] >> 6);
+        int64_t slot = (int64_t)(((__int128)r53 * b->n) >> 53);
+        int32_t col = (int32_t)slot;
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        if (b->has_anc) HIPCHECK(hipMemcpy(&col, b->anc + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<int32_t> h((size_t)b->rows);
+        HIPCHECK(hipMemcpy2D(h.data(), sizeof(int32_t), b->buf[b->cur] + col, sizeof(int32_t) * (size_t)b->stride, sizeof(int32_t), (size_t)b->rows, hipMemcpyDeviceToHost));
+        if (S) *S = h[0];
+        if (R) *R = h[1];
+        if (I) for (int i = 0; i < H; i++) I[i] = h[(size_t)(2 + i)];
+        if (T) {
+            for (int j = 0; j < D1 * H; j++) T[j] = 0;
+            for (int cidx = 1; cidx < H; cidx++)
+                for (int r = 0; r < D; r++) T[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx)];
+        }
+        return EPI_OK;
+    });
 }
 
 } // extern "C"

@@ -55,7 +55,7 @@ EPI_HD Rng rng_make(uint64_t seed, uint64_t slot, uint32_t step)
 // not select for a chain of two exclusive-ors by itself.
 EPI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(EPI_NO_BITOP3)
+#if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 #else
     return a ^ b ^ c;
@@ -87,31 +87,9 @@ EPI_HD void rng_block(const Rng& g, uint32_t kind, uint32_t bin, uint32_t blk, u
     philox4x32_10(g.c0, g.c1, g.c2, (kind << 24) | (bin << 8) | blk, g.k0, g.k1, w);
 }
 
-// uniform in (0,1): (w + 1/2) 2^-32, exact in binary64.  (EPI_U01_BITS builds the same value from the bits of
-// 1 + (w + 1/2) 2^-32 and one subtraction; measured slower on gfx950 on three occasions, kept as a build switch.)
-#ifdef EPI_U01_BITS
-EPI_HD double u01_plus1(uint32_t w)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t hi = __builtin_amdgcn_alignbit(0x3FFu, w, 12);       // 0x3FF00000 | w >> 12
-    const uint32_t lo = (w << 20) | 0x80000u;
-    return u2d(((uint64_t)hi << 32) | lo);
-#else
-    return u2d(0x3FF0000000080000ULL | ((uint64_t)w << 20));
-#endif
-}
-EPI_HD double u01(uint32_t w) { return u01_plus1(w) - 1.0; }
-EPI_HD double u01_centred(uint32_t w) { return u01_plus1(w) - 1.5; }
-#elif defined(EPI_U01_FMA)
-// One fused multiply-add each: w 2^-32 + 2^-33 and w 2^-32 + (2^-33 - 1/2) are exact in binary64 (33 significant bits).
-// Two instructions fewer per pair of uniforms, yet slower (23.49 against 23.26 ms for the step kernel): the two
-// constants are not inline operands and take scalar registers that the sampler phases are short of.
-EPI_HD double u01(uint32_t w) { return __builtin_fma((double)w, 0x1p-32, 0x1p-33); }
-EPI_HD double u01_centred(uint32_t w) { return __builtin_fma((double)w, 0x1p-32, 0x1p-33 - 0.5); }
-#else
+// uniform in (0,1): (w + 1/2) 2^-32, exact in binary64
 EPI_HD double u01(uint32_t w) { return ((double)w + 0.5) * 0x1p-32; }
 EPI_HD double u01_centred(uint32_t w) { return u01(w) - 0.5; }
-#endif
 
 // ---- elementary functions ---------------------------------------------------
 
@@ -119,10 +97,9 @@ EPI_HD double u01_centred(uint32_t w) { return u01(w) - 0.5; }
 // forms are the compiler's own expansions (hardware estimate, accurate to one ulp, plus the rounding correction)
 // without the operand scaling and the special-case fix-up that only subnormal, huge or non-finite operands need:
 // every call site keeps its operands between 2^-30 and 2^32 (or exactly zero, which both forms map to zero).
-// EPI_PLAIN_F32 restores the compiler's expansions; the kernel results are the same bits either way.
 EPI_HD float sqrt_rn(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(EPI_PLAIN_F32)
+#if defined(__HIP_DEVICE_COMPILE__)
     const float r = __builtin_amdgcn_sqrtf(x);
     const float lo = u2f(f2u(r) - 1u), hi = u2f(f2u(r) + 1u);
     const float el = __builtin_fmaf(-lo, r, x), eh = __builtin_fmaf(-hi, r, x);
@@ -136,7 +113,7 @@ EPI_HD float sqrt_rn(float x)
 
 EPI_HD float div_rn(float n, float d)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(EPI_PLAIN_F32)
+#if defined(__HIP_DEVICE_COMPILE__)
     float r = __builtin_amdgcn_rcpf(d);
     r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
     float q = n * r;
@@ -496,7 +473,7 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
     const double kd = btrs_k(C, u, us);
     if (kd < 0.0 || kd > C.nd) return -1;
     if (us >= 0.07 && v <= C.vr) return (int32_t)kd;
-#if defined(EPI_HAVE_SCREEN) && !defined(EPI_NO_LV_FIRST)
+#if defined(EPI_HAVE_SCREEN)
     // the table loads of the right side are issued first and the binary32 estimate of the left side, which does not
     // depend on them, is computed while they are in flight
     if (C.nd < (double)C.lf.n) {
@@ -538,7 +515,6 @@ __device__ __forceinline__ int32_t btrs_try(BtrsConsts& C, int32_t n, double pp,
                                             uint32_t wa, uint32_t wb)
 {
     btrs_consts_k(C, n, pp, lpq, lf, screen);
-#ifndef EPI_NO_BTRS_TRY
     if (C.nd < (double)lf.n) {
         const double u = u01_centred(wa);
         const double us = 0.5 - __builtin_fabs(u);
@@ -570,7 +546,6 @@ __device__ __forceinline__ int32_t btrs_try(BtrsConsts& C, int32_t n, double pp,
         if (inr && !acc && !(diff > guard)) res = btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? ki : -1;
         return res;
     }
-#endif
     btrs_consts_rest(C);
     return btrs_attempt(C, wa, wb);
 }

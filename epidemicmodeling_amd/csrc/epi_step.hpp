@@ -213,7 +213,7 @@ struct BinOut { int32_t ipost; double mean, sd2; };
 // for such operands.  Same steps in the same order: the same bits.  (Device code only; the host divides.)
 EPI_HD double div_unscaled(double a, double b)
 {
-#if defined(EPI_NO_SHORT_DIV) || !defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__HIP_DEVICE_COMPILE__)
     return a / b;
 #else
     const double r0 = __builtin_amdgcn_rcp(b);

@@ -44,10 +44,12 @@ class LibShard:
     """The local shard, held by libepi_gfx950.so on one device."""
 
     def __init__(self, pomdp: CovidPOMDP, n_local: int, n_total: int, slot0: int, device: int):
-        from .interface import ParticleCollection, context_for
+        from .interface import Context, ParticleCollection
         import torch
         self.torch = torch
-        self.ctx = context_for(pomdp, device)
+        # a context of its own (not the process-wide cached one): the shard moves the context onto torch's stream, and
+        # other collections on the same device must not follow it there
+        self.ctx = Context(pomdp, device)
         self.lib = self.ctx.lib
         self.b = ParticleCollection(self.ctx, n_local, halo_cap=n_local if n_total > n_local else 0)
         check(self.lib.epi_belief_set_shard(self.b.handle, n_total, slot0))
@@ -55,9 +57,27 @@ class LibShard:
         self.comm_device = torch.device("cuda", device)
         # the library works on torch's current stream, where the RCCL collectives are ordered too: the phases of
         # an update are then only enqueued, and the host waits once per update (for the weight totals)
-        self.stream = torch.cuda.current_stream(self.comm_device)
-        check(self.lib.epi_ctx_set_stream(self.ctx.handle, C.c_void_p(self.stream.cuda_stream), 1))
+        self.stream = None
+        self.adopt_current_stream()
         self.shares_stream = True
+
+    def adopt_current_stream(self):
+        """Called at the top of every update: the library's kernels must run on the stream the collectives of this
+        update are ordered on, i.e. torch's current one (it changes under `with torch.cuda.stream(...)`)."""
+        cur = self.torch.cuda.current_stream(self.comm_device)
+        if self.stream is None or cur.cuda_stream != self.stream.cuda_stream:
+            self.stream = cur
+            check(self.lib.epi_ctx_set_stream(self.ctx.handle, C.c_void_p(cur.cuda_stream), 1))
+
+    def close(self):
+        """Frees the shard; the context goes back to its own stream before it is destroyed."""
+        if self.b is not None:
+            self.b.close()
+            self.b = None
+        if self.ctx is not None:
+            self.lib.epi_ctx_set_stream(self.ctx.handle, None, 0)
+            self.ctx.close()
+            self.ctx = None
 
     def init_normal(self, mu, sigma, seed):
         check(self.lib.epi_belief_init_normal(self.b.handle, mu, sigma, seed))
@@ -196,6 +216,8 @@ class ShardedFilter:
         G, g, seed, step = self.world, self.rank, self.seed, self.step
         sh = self.shard
         device_handover = hasattr(sh, "predict_dev")
+        if hasattr(sh, "adopt_current_stream"):
+            sh.adopt_current_stream()
         if device_handover:
             # 1-4 without a host round trip: the library's kernels and the collectives are ordered on one stream
             t = torch.empty(1, dtype=torch.float64, device=self.comm_device)
@@ -259,6 +281,10 @@ class ShardedFilter:
         loglik = (lwmax + math.log(W / 2.0 ** self.frac_bits / self.n_total) - 0.5 * math.log(2 * math.pi)) if W else float("-inf")
         return {"loglik": loglik, "ess": (float(W) ** 2 / sumsq) if sumsq > 0 else 0.0, "flags": flags,
                 "moved": sum(r1 - r0 for r0, r1, _ in recvs), "w_shard": w_shard, "lo": lo}
+
+    def close(self):
+        if hasattr(self.shard, "close"):
+            self.shard.close()
 
     # -- summaries ----------------------------------------------------------
     def mean(self):

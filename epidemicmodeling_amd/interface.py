@@ -194,6 +194,13 @@ def random_states(pomdp: CovidPOMDP, n: int, seed: int = _DEFAULT_SEED, device: 
     return b
 
 
+def _prev_prop(b: "ParticleCollection") -> float:
+    if b.prev_action is None:
+        raise ValueError("the collection's last step used one action per particle, so it has no single previous action; "
+                         "step it once with a common action, or pass a_prev where the call takes it")
+    return b.prev_action.testing_prop
+
+
 # ---------------------------------------------------------------------------
 # generative model
 # ---------------------------------------------------------------------------
@@ -207,6 +214,8 @@ def step_batch(b: ParticleCollection, a, a_prev=None, seed: int = _DEFAULT_SEED,
     if a_arr.size not in (1, n):
         raise ValueError("a must be a scalar or have one entry per particle")
     if a_prev is None:
+        if b.prev_action is None:
+            raise ValueError("the previous step used one action per particle: pass a_prev (one value per particle) explicitly")
         a_prev = b.prev_action.testing_prop
     ap_arr = np.ascontiguousarray(np.atleast_1d(np.asarray(a_prev, dtype=np.float64)))
     if ap_arr.size not in (1, n):
@@ -217,8 +226,8 @@ def step_batch(b: ParticleCollection, a, a_prev=None, seed: int = _DEFAULT_SEED,
     flags = C.c_uint32(0)
     check(b.ctx.lib.epi_step_batch(b.ctx.handle, b.handle, as_f64p(a_arr), per, as_f64p(ap_arr), pper, seed, step,
                                    as_i64p(o), as_f64p(r), None, C.byref(flags)))
-    if a_arr.size == 1:
-        b.prev_action = Action(float(a_arr[0]))
+    # after a step with one action per particle the collection has no single previous action any more
+    b.prev_action = Action(float(a_arr[0])) if a_arr.size == 1 else None
     return o, r, flags.value
 
 
@@ -278,6 +287,13 @@ def update(upd: BootstrapFilter, b: ParticleCollection, a: Action, o: int, copy:
     systematic resample (src/POMDPsInterface.jl:56).  In place unless copy=True."""
     if b.n != upd.n:
         raise ValueError("belief size differs from the filter's particle count")
+    if upd.pomdp.test_period != 1:
+        # the device update predicts with ONE SimStep; a filter on a model with test_period > 1 would predict through
+        # gen's test_period sub-steps (src/POMDPsInterface.jl:1-9).  The reference's closed loop builds its filter on
+        # unity_test_period(pomdp) (src/POMDPsInterface.jl:38-39): do the same.
+        raise ValueError("BootstrapFilter needs a model with test_period == 1: build it on unity_test_period(pomdp)")
+    if unity_test_period(upd.pomdp) != unity_test_period(b.ctx.pomdp):
+        raise ValueError("the filter's model differs from the model the belief was created for")
     if copy:
         b = b.copy()
     ll, ess, flags = C.c_double(), C.c_double(), C.c_uint32()
@@ -363,7 +379,7 @@ def rollout_batch(b: ParticleCollection, T: int, actions, seed: int = _DEFAULT_S
     hist = np.empty((n, T, 4), dtype=np.int64) if want_hist else None
     rew = np.empty((n, T), dtype=np.float64) if want_rew else None
     flags = C.c_uint32()
-    check(b.ctx.lib.epi_rollout_batch(b.ctx.handle, b.handle, T, as_f64p(act), per_p, per_d, b.prev_action.testing_prop,
+    check(b.ctx.lib.epi_rollout_batch(b.ctx.handle, b.handle, T, as_f64p(act), per_p, per_d, _prev_prop(b),
                                       seed, step0, as_i64p(hist), as_f64p(rew), C.byref(flags)))
     return hist, rew, flags.value
 
@@ -384,7 +400,7 @@ def rollout_score(b: ParticleCollection, actions, rollouts_per_seq: int = 1, dis
     score = np.empty(n_seq, dtype=np.float64)
     flags = C.c_uint32()
     check(b.ctx.lib.epi_rollout_score(b.ctx.handle, b.handle, n_seq, int(rollouts_per_seq), T, as_f64p(act),
-                                      b.prev_action.testing_prop, disc, seed, step0, as_f64p(score), C.byref(flags)))
+                                      _prev_prop(b), disc, seed, step0, as_f64p(score), C.byref(flags)))
     return score, flags.value
 
 

@@ -52,6 +52,15 @@ extern "C" {
 #define EPI_F_NEG_NT     2u /* a tested count was negative                          */
 #define EPI_F_BAD_DENOM  4u /* N - R <= 0 in incident_infections (simulate.jl:42)   */
 #define EPI_F_ZERO_W     8u /* every particle weight was zero: particles kept       */
+/* Degenerate weights, where this library and ParticleFilters.jl differ (the reference's own behaviour there is NaN
+ * arithmetic, not a specification):
+ *   - Normal(mu, 0) (no one tested, or every test probability 0 or 1): a particle whose mu equals o gets weight 1
+ *     (log weight 0, to which the constant -log sqrt(2 pi) of the log-likelihood still applies), any other weight 0;
+ *     the reference's pdf is Inf / 0 there.
+ *   - every weight zero: the particles are kept in place and EPI_F_ZERO_W is raised; the reference's low-variance
+ *     resampler would return n copies of its first particle (its cumulative-weight walk never advances).
+ * The samplers cap a rejection draw at 512 attempts (probability of reaching it below 10^-400 for any admissible
+ * parameters); a draw that exhausted them would differ between the two step kernels. */
 
 /* Model parameters the step needs: the numeric content of the reference's
  * CovidPOMDP struct (src/typedef.jl:43-56) after its constructor has run
@@ -108,6 +117,7 @@ int epi_belief_copy(epi_belief *dst, epi_belief *src);
 /* Initial particles generated on the device.
  * epi_belief_init_normal: State(Normal(mu, sigma), params) per particle
  *   (src/typedef.jl:159-181; the stale test/POMCPOWtest.jl:8-10 initialstate).
+ *   Returns EPI_EINVAL if any particle drew sum(I0) > N (the reference asserts, src/typedef.jl:164).
  * epi_belief_init_simplex: State(params) per particle (src/typedef.jl:196-217). */
 int epi_belief_init_normal(epi_belief *b, double mu, double sigma, uint64_t seed);
 int epi_belief_init_simplex(epi_belief *b, uint64_t seed);
@@ -298,23 +308,6 @@ int epi_ctx_set_stream(epi_ctx *ctx, void *hip_stream, int adopt);
  * device until epi_pf_collect. */
 int epi_pf_update_async(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step);
 int epi_pf_collect(epi_ctx *ctx, epi_belief *b, double *loglik, double *ess, uint32_t *flags);
-/* The rejection samplers screen most accept/reject tests in binary32 before
- * evaluating the defining binary64 expression; results are identical either
- * way.  enable = 0 forces the binary64 expression everywhere (testing aid,
- * process-wide). */
-int epi_debug_screen(int enable);
-/* The samplers take binary32 square roots and quotients whose operands are known to lie between 2^-30 and
- * 2^32; on the device they use the hardware estimate plus the rounding correction, without the scaling and
- * special-case steps of the general expansion.  This self-check evaluates both forms on every binary32 value in
- * [first, last] (mode 0: sqrt(x); 1: 1/x; 2: f/(2+f) with f = x-1, the quotient inside the binary32 logarithm)
- * and returns the number of values where the bits differ (must be 0).  No counterpart in the reference. */
-int epi_debug_f32_forms(epi_ctx *ctx, int mode, float first, float last, uint64_t *mismatches);
-/* Two implementations of the Philox-driven step kernel give identical results: the cooperative one
- * hands rejected sampler attempts to idle threads of the workgroup, the other loops per thread.
- * cooperative = 1 (default) picks by state width (cooperative up to H = 15, where its LDS footprint still
- * leaves four workgroups per CU), 2 forces the cooperative kernel, 0 the per-thread one.  Testing aid,
- * process-wide. */
-int epi_debug_step_impl(int cooperative);
 /* With timing enabled every filter update brackets its fused step kernel with a
  * pair of HIP events on the context's stream; epi_ctx_timing_read waits for the
  * stream, returns the summed kernel time (ms) and the number of launches since

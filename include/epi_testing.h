@@ -1,0 +1,37 @@
+/*
+ * epi_testing.h -- entry points that exist only in libepi_gfx950_testing.so, the build of the library made with
+ * -DEPI_TESTING for its own test suite.  They switch process-wide implementation choices that never change a result
+ * (the tests that use them show exactly that); the product library has neither the switches nor the alternative
+ * kernels.  No counterpart in the reference.
+ */
+#ifndef EPI_TESTING_H
+#define EPI_TESTING_H
+
+#include "epi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The rejection samplers screen most accept/reject tests in binary32 before
+ * evaluating the defining binary64 expression; results are identical either
+ * way.  enable = 0 forces the binary64 expression everywhere (testing aid,
+ * process-wide). */
+int epi_debug_screen(int enable);
+/* The samplers take binary32 square roots and quotients whose operands are known to lie between 2^-30 and
+ * 2^32; on the device they use the hardware estimate plus the rounding correction, without the scaling and
+ * special-case steps of the general expansion.  This self-check evaluates both forms on every binary32 value in
+ * [first, last] (mode 0: sqrt(x); 1: 1/x; 2: f/(2+f) with f = x-1, the quotient inside the binary32 logarithm)
+ * and returns the number of values where the bits differ (must be 0).  No counterpart in the reference. */
+int epi_debug_f32_forms(epi_ctx *ctx, int mode, float first, float last, uint64_t *mismatches);
+/* Two implementations of the Philox-driven step kernel give identical results: the cooperative one
+ * hands rejected sampler attempts to idle threads of the workgroup, the other loops per thread.
+ * cooperative = 1 (default) picks by state width (cooperative up to H = 15, where its LDS footprint still
+ * leaves four workgroups per CU), 2 forces the cooperative kernel, 0 the per-thread one.  Testing aid,
+ * process-wide. */
+int epi_debug_step_impl(int cooperative);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPI_TESTING_H */

@@ -11,14 +11,23 @@ from epidemicmodeling_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "epi.h")).read()
+def _declared(header="epi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(epi_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():
     assert _declared() == sorted(_lib.SIGNATURES)
+
+
+def test_testing_build_has_the_switches_and_the_product_does_not():
+    assert _declared("epi_testing.h") == sorted(_lib.TESTING_SIGNATURES)
+    product, testing = _lib.load(), _lib.load_testing()
+    for name in _lib.TESTING_SIGNATURES:
+        assert hasattr(testing, name) and not hasattr(product, name), name
+    for name in _lib.SIGNATURES:
+        assert hasattr(testing, name), name
 
 
 def test_library_exports_every_declared_symbol():

@@ -13,7 +13,7 @@ import pytest
 from conftest import random_states, reference_test_params
 import epidemicmodeling_amd as em
 from epidemicmodeling_amd import _lib
-from epidemicmodeling_amd._lib import as_f64p, as_i64p, check
+from epidemicmodeling_amd._lib import EpiError, as_f64p, as_i64p, check
 from oracle import pyoracle
 
 pytestmark = pytest.mark.gpu
@@ -192,6 +192,15 @@ def test_initial_beliefs_bit_exact():
     _eq(b.download(), orc.init_normal(10_000, 10_000.0, 5_000.0, 5))
     b2 = em.random_states(pomdp, 10_000, seed=6)
     _eq(b2.download(), orc.init_simplex(10_000, 6))
+
+
+def test_initial_belief_larger_than_the_population_is_refused():
+    """State(Normal(mu, sigma), params) asserts sum(I0) <= N (src/typedef.jl:164): 14 bins of about 10^5 in a
+    population of 10^6 violate it."""
+    pomdp = em.make_pomdp(LOD=5)
+    with pytest.raises(EpiError, match="typedef.jl:164") as e:
+        em.initialbelief(pomdp, 1000, mu=100_000.0, sigma=1_000.0, seed=3)
+    assert e.value.code == -1
 
 
 def test_belief_mean_and_sample():
@@ -481,10 +490,10 @@ def _three_updates(pomdp, n):
 
 
 @pytest.mark.parametrize("delay", [0, 1])
-def test_step_implementations_and_screens_agree(delay):
+def test_step_implementations_and_screens_agree(delay, testing_lib):
     """Cooperative (LDS retry queues) vs one-thread-per-particle kernel, binary32 screens on vs
     off: four builds of the same update, bit-identical posteriors at 10^6 particles."""
-    lib = _lib.load()
+    lib = testing_lib
     pomdp = em.make_pomdp(LOD=5, test_delay=delay)
     n = 1_000_000
     try:
@@ -500,7 +509,7 @@ def test_step_implementations_and_screens_agree(delay):
         check(lib.epi_debug_screen(1))
 
 
-def test_short_binary32_sqrt_and_quotient_are_correctly_rounded():
+def test_short_binary32_sqrt_and_quotient_are_correctly_rounded(testing_lib):
     """The device forms of the binary32 square root and quotient used by the samplers against
     the compiler's general expansions (what the host oracle's sqrtf and "/" compute), on EVERY
     binary32 value of the operand ranges: sqrt over [2^-30, 2^32), 1/x over [1, 2^20), and the
@@ -515,10 +524,10 @@ def test_short_binary32_sqrt_and_quotient_are_correctly_rounded():
     assert ctx.lib.epi_debug_f32_forms(ctx.handle, 3, 1.0, 2.0, C.byref(bad)) == -1        # EPI_EINVAL
 
 
-def test_wide_state_retry_queue_overflow_bit_exact():
+def test_wide_state_retry_queue_overflow_bit_exact(testing_lib):
     """H = 56 infection ages: 112 binomial draws per particle, so a workgroup's rejected first
     attempts exceed the retry queue and the in-thread completion path runs; still bit-exact."""
-    lib = _lib.load()
+    lib = testing_lib
     pomdp = em.make_pomdp(LOD=5, horizon=56, test_delay=1)
     orc = pyoracle.Oracle(pomdp.to_c())
     n = 3000
