@@ -16,6 +16,8 @@ EPI_F_NEG_I = 1
 EPI_F_NEG_NT = 2
 EPI_F_BAD_DENOM = 4
 EPI_F_ZERO_W = 8
+EPI_F_COARSE_W = 16
+COARSE_W_BOUND = 1e-3      # EPI_F_COARSE_W: n_total / (fixed-point weight total) above this
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # EPI_GFX950_LIB points at another build of the same library (kernel A/B measurements); there is still no fallback.
@@ -81,6 +83,8 @@ SIGNATURES = {
     "epi_ensemble_loss": (C.c_int, [_vp, _vp, C.c_int, _f64p, C.c_int, C.c_int, _f64p, _f64p]),
     "epi_pf_update": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p]),
     "epi_pf_update_noalloc": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p]),
+    "epi_closed_loop_days": (C.c_int, [_vp, _vp, _vp, C.c_int, _f64p, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                                       C.c_int, _f64p, _i64p, _f64p, _i64p, _f64p, _f64p, _u32p, _i64p, _i64p]),
     "epi_pf_frac_bits": (C.c_int, [C.c_int64]),
     "epi_pf_predict": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p]),
     "epi_pf_weigh": (C.c_int, [_vp, _vp, C.c_double, _u64p, _f64p, _u32p]),

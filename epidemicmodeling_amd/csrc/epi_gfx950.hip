@@ -119,6 +119,9 @@ struct epi_ctx {
     // runs one call at a time, and every call that uses them has waited for the stream before it returns.
     unsigned char* h_pin = nullptr;     // PIN_BYTES of page-locked host memory
     unsigned char* d_small = nullptr;   // SMALL_BYTES of device scratch
+    unsigned char* d_days = nullptr;    // per-day records of epi_closed_loop_days (grown on demand)
+    size_t days_cap = 0;
+    unsigned char* d_qsel = nullptr;    // histograms (QSEL_HIST_BYTES, zero between calls) and state of the order-statistic selection
     unsigned char* d_static = nullptr;  // this device's copy of the file-scope scratch array of epi_pf_update_noalloc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -163,6 +166,7 @@ static const int LF_TABLE_N = 1 << 20; // tabulated log factorials (8 MB per con
 static const int SCAN_ITEMS = 8;       // fixed-point weights per thread in the scan kernels
 static const int SCAN_TILE = TPB * SCAN_ITEMS;
 
+static const size_t QSEL_HIST_BYTES = 4 * 2048 * sizeof(unsigned long long);   // histograms of the order-statistic selection (k_qsel_hist)
 static const size_t PIN_BYTES = 128 << 10;
 static const size_t SMALL_BYTES = 128 << 10;
 
@@ -214,6 +218,7 @@ struct StepArgs {
     uint64_t seed; uint32_t step; uint64_t slot0;
     // filter
     double o; double* lw; DevScalars* scal;
+    const int32_t* o_dev;       // when set, the observation is read from device memory (written by an earlier kernel on the stream) instead of `o`
     // optional per-particle outputs
     int32_t* o_out; double* r_out; int32_t* newinf_out;
     // optional history row of a rollout: hist[c * n + m], c = 0..3
@@ -225,6 +230,8 @@ struct StepArgs {
     int32_t* rec_sympt; int32_t* rec_pos; double* rec_gam;
     int screen;                 // 1: the rejection samplers may use their binary32 screens
     int64_t block0;             // k_step_coop: index of the launch's first workgroup within the population
+    int padded;                 // the rows of `out` and `lw` extend to a multiple of 256 particles: the build without bounds checks may
+                                // run the last, partial workgroup too (its surplus threads step copies of the last particle into the padding)
 };
 
 enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(TPB, THREAD_WAVES) void k_step(const StepArgs A, co
         }
         flags = res.flags;
         if constexpr (WEIGH) {
-            double lw = log_weight(res.mu, res.var, A.o);
+            double lw = log_weight(res.mu, res.var, A.o_dev ? (double)*A.o_dev : A.o);
             A.lw[m] = lw;
             code = order_code(lw);
         }
@@ -291,6 +298,93 @@ __global__ __launch_bounds__(TPB, THREAD_WAVES) void k_step(const StepArgs A, co
             for (int w = 1; w < TPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
             atomicMax(&A.scal->lwmax_bits, c);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_step_one: the step of a population of ONE particle (the true state of a closed loop, POMDPs.gen on a single state,
+// Simulate), one lane per infection age in a single wavefront.  The two other kernels take a lone particle through its
+// 3 H draws one after the other (40-50 us of dependent latency); here every age bin draws at once.  Same variates
+// (addressed by slot, step, bin), same operations per bin, the infection sum added in bin order: the same bits.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_step_one(const StepArgs A, const DevParams* __restrict__ Dp)
+{
+    const epi_params& P = Dp->P;
+    const int H = P.H, D = P.D;
+    const int i = threadIdx.x;                                  // age bin of this lane (and its infection term)
+    const bool act = i < H;
+    const int64_t src = A.anc ? (int64_t)A.anc[0] : 0;
+    const double a = A.a_dev ? A.a_dev[A.a_col] : A.a;
+    const Rng g = rng_make(A.seed, A.slot0, A.step);
+    const bool screen = A.screen != 0;
+    unsigned int flags = 0;
+    int32_t r_add = 0, pos = 0, ipost = 0, I_pre = 0;
+    if (act) {
+        int32_t Ii = A.in[(int64_t)(2 + i) * A.in_stride + src];
+        I_pre = Ii;
+        int32_t already = 0;
+        if (D > 0 && i >= 1)
+            for (int r = 0; r < D; r++) already += A.in[(int64_t)tests_row(H, r, i) * A.in_stride + src];
+        const double ntf = __builtin_floor((double)(Ii - already) * a);                    // simulate.jl:78
+        const int32_t nt = (int32_t)ntf;
+        if (nt < 0) flags |= EPI_F_NEG_NT;
+        uint32_t w[4];
+        rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
+        const int32_t sympt = bin_binomial(*Dp, i, 0, Ii, w[0], w[1], g, screen);        // simulate.jl:58
+        pos = bin_binomial(*Dp, i, 1, nt, w[2], w[3], g, screen);                        // simulate.jl:79
+        double pr = div_unscaled((double)sympt, (double)Ii);                             // simulate.jl:104
+        if (pr != pr) pr = 0.0;                                                          // simulate.jl:105
+        const double om = 1.0 - pr;
+        r_add = sympt; Ii -= sympt;                                                      // simulate.jl:107-108
+        for (int r = 0; r <= D; r++) {                                                   // simulate.jl:110-126
+            int32_t tv;
+            if (r == D) tv = pos;
+            else tv = (i >= 1) ? A.in[(int64_t)tests_row(H, r, i) * A.in_stride + src] : 0;
+            const int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
+            if (r == 0) { r_add += ts; Ii -= ts; }
+            else if (i + 1 < H) A.out[(int64_t)tests_row(H, r - 1, i + 1) * A.out_stride] = ts;
+        }
+        if (Ii < 0) flags |= EPI_F_NEG_I;                                                // simulate.jl:117
+        ipost = Ii;
+        if (A.pos_out) A.pos_out[i] = pos;
+    }
+    // infection term `it` is seeded by the survivors of bin it - 1, term 0 by those of the last bin (simulate.jl:144-145)
+    const int from = i == 0 ? H - 1 : i - 1;
+    const int32_t seedling = __shfl(ipost, from, 64);
+    double gval = 0.0;
+    if (act) {
+        if (i >= 1) A.out[(int64_t)(2 + i) * A.out_stride] = seedling;
+        float zf; uint32_t wu;
+        gamma_first(g, (uint32_t)i, zf, wu);
+        gval = gamma_draw(P.k[i] * (double)seedling, P.theta[i], zf, wu, g, (uint32_t)i, screen);   // simulate.jl:40, init.jl:71-78
+    }
+    int32_t r_sum = r_add, o_sum = pos, pre_sum = I_pre, post_sum = (act && i >= 1) ? seedling : 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        r_sum += __shfl_down(r_sum, d, 64); o_sum += __shfl_down(o_sum, d, 64);
+        pre_sum += __shfl_down(pre_sum, d, 64); post_sum += __shfl_down(post_sum, d, 64);
+        flags |= __shfl_down(flags, d, 64);
+    }
+    const int32_t last_post = __shfl(ipost, H - 1, 64);
+    double infsum = 0.0;
+    for (int it = 0; it < H; it++) infsum += u2d(((uint64_t)__shfl((unsigned int)(d2u(gval) >> 32), it, 64) << 32) | __shfl((unsigned int)d2u(gval), it, 64));   // in term order
+    if (i == 0) {
+        const int32_t S = A.in[src], R_pre = A.in[A.in_stride + src];
+        const int32_t R = R_pre + r_sum + last_post;                                     // simulate.jl:107,115,144
+        const int64_t denom = P.N - (int64_t)R;
+        int32_t newi = 0;
+        if (denom <= 0) flags |= EPI_F_BAD_DENOM;
+        else newi = (int32_t)__builtin_floor(div_unscaled((double)S, (double)denom) * infsum);     // simulate.jl:42-44
+        A.out[(int64_t)2 * A.out_stride] = newi;                                         // simulate.jl:147
+        A.out[0] = S - newi;                                                             // simulate.jl:148
+        A.out[A.out_stride] = R;
+        if (A.o_out) A.o_out[0] = o_sum;
+        if (A.newinf_out) A.newinf_out[0] = newi;
+        if (A.r_out) {
+            const double ap = A.a_prev_dev ? A.a_prev_dev[A.a_prev_col] : A.a_prev;
+            A.r_out[0] = reward_of(P, post_sum + newi, a, ap);
+        }
+        if (A.hist) { A.hist[0] = S; A.hist[1] = pre_sum; A.hist[2] = R_pre; A.hist[3] = o_sum; }
+        if (flags) atomicOr(&A.scal->flags, flags);
     }
 }
 
@@ -358,7 +452,10 @@ constexpr int COOP_WAVES = 4;   // waves per SIMD the register allocation aims a
 // HC > 0: the number of infection ages is this constant (the reference's default horizon has a build of its own).
 // SCREEN: the rejection samplers use their binary32 screens (a compile-time constant in the production builds: the
 // flag only selects code, never a result; the builds without screens exist for the test that shows exactly that).
-// FULL: the population fills every workgroup of the grid (no thread needs the bounds check).
+// FULL: no thread needs the bounds check: either the population fills every workgroup of the grid, or the output rows
+// are padded to whole workgroups and the surplus threads of the last one step copies of the last particle into the
+// padding (their optional outputs and flags are dropped; their log weight equals the last particle's, so the maximum
+// is unchanged).
 template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true, bool FULL = false>
 __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
@@ -381,8 +478,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     const int64_t base = ((int64_t)blockIdx.x + A.block0) * CTPB;
     const int64_t m = base + tid;
     const bool active = FULL ? true : m < A.n;
-    const int64_t src = active ? (A.anc ? (int64_t)A.anc[m] : m) : 0;
-    const int64_t arow = A.a_div > 1 ? m / A.a_div : m;
+    const int64_t mc = FULL ? (m < A.n ? m : A.n - 1) : m;                         // the particle this thread reads
+    const int64_t src = active ? (A.anc ? (int64_t)A.anc[mc] : mc) : 0;
+    const int64_t arow = A.a_div > 1 ? mc / A.a_div : mc;
     const double a = active ? (A.a_dev ? A.a_dev[arow * A.a_row_stride + A.a_col] : A.a) : 0.0;
     const Rng g = rng_make(A.seed, A.slot0 + (uint64_t)m, A.step);
     const bool screen = SCREEN;
@@ -437,8 +535,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             }
         }
         if constexpr (WEIGH) {
-            const double lw = log_weight(tm, tv, A.o);
-            EPI_STREAM_STORE(&(A.lw + base)[tid], lw);
+            const double lw = log_weight(tm, tv, Ak->o_dev ? (double)*Ak->o_dev : Ak->o);
+            EPI_STREAM_STORE(&(Ak->lw + base)[tid], lw);
             code = order_code(lw);
         }
     }
@@ -658,14 +756,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         st_out(2, newi);                                                                        // simulate.jl:147
         st_out(0, S - newi);                                                                    // simulate.jl:148
         st_out(1, R);
-        if (Ak->o_out) Ak->o_out[m] = o_sum;
-        if (Ak->newinf_out) Ak->newinf_out[m] = newi;
-        if (Ak->r_out) {
+        const bool real = !FULL || m < Ak->n;                                                   // not a surplus thread of a padded launch
+        if (!real) flags = 0u;
+        if (Ak->o_out && real) Ak->o_out[m] = o_sum;
+        if (Ak->newinf_out && real) Ak->newinf_out[m] = newi;
+        if (Ak->r_out && real) {
             const int64_t prow = Ak->a_div > 1 ? m / Ak->a_div : m;
             const double ap = Ak->a_prev_dev ? Ak->a_prev_dev[prow * Ak->a_row_stride + Ak->a_prev_col] : Ak->a_prev;
             Ak->r_out[m] = reward_of(P, sum_inf + newi, a, ap);
         }
-        if (Ak->hist) {
+        if (Ak->hist && real) {
             int32_t* hist = Ak->hist;
             const int64_t hn = Ak->n;
             hist[m] = S; hist[hn + m] = suminf_pre; hist[2 * hn + m] = R_pre; hist[3 * hn + m] = o_sum;
@@ -701,6 +801,10 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
     // The cooperative kernel takes the square root of the observation variance without the power-of-two scaling that
     // arguments below 2^-767 need; the argument is a positive integer times p (1 - p), so a parameter set with a test
     // probability in (0, 2^-700) always runs the per-thread kernel.
+    if (!WEIGH && A.n == 1 && g_coop == 1) {                    // a lone particle: one lane per age bin
+        k_step_one<<<dim3(1), dim3(64), 0, c->stream>>>(A, c->d_params);
+        return hipGetLastError();
+    }
     const size_t lds = coop_lds_bytes(c->P.H);
     if (!c->tiny_p && (g_coop == 2 || (g_coop == 1 && lds <= 40 * 1024))) {
         if (lds > 64 * 1024) {
@@ -720,9 +824,9 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         else if (c->P.H == 14) {
             // the workgroups that the population fills run the build without the per-thread bounds check; the last,
             // partial one (if any) is a launch of its own
-            const int64_t full = A.n / CTPB;
+            const int64_t full = A.padded ? ceil_div(A.n, CTPB) : A.n / CTPB;
             if (full > 0) k_step_coop<WEIGH, false, 14, true, true><<<dim3((unsigned)full), dim3(CTPB), lds, c->stream>>>(A, c->d_params);
-            if (A.n % CTPB != 0) {
+            if (!A.padded && A.n % CTPB != 0) {
                 StepArgs T = A;
                 T.block0 = full;
                 k_step_coop<WEIGH, false, 14><<<dim3(1), dim3(CTPB), lds, c->stream>>>(T, c->d_params);
@@ -1250,38 +1354,292 @@ __global__ __launch_bounds__(TPB) void k_init_simplex(int64_t n, int32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
-// order statistics of the infected total sum(I) over the particles of a belief (radix select, 11 + 11 + 9 bits)
+// order statistics of the infected total sum(I) over the particles of a belief
+//
+// Exact selection by narrowing windows, entirely on the device.  The kernel that computes the totals also finds their
+// minimum and maximum; the window [lo, lo + 2^W) starts as the smallest power-of-two span from the minimum that holds
+// every value.  Each pass histograms the values of the window into 2048 bins of 2^max(W - 11, 0), finds per quantile
+// the bin in which the wanted rank falls and makes that bin the next window; W = 0 ends it (at most three passes for
+// 31-bit values, two for the default population).  The first pass is common to all quantiles.  Every kernel's
+// workgroups add their LDS histograms to the global one; the workgroup that finishes last (a ticket) does the
+// narrowing and leaves histogram and ticket cleared, so the buffers are zero between calls.
 // ---------------------------------------------------------------------------
 constexpr int QSEL_MAX = 4;            // quantiles per call
 constexpr int QSEL_BINS = 2048;
+constexpr int QSEL_LOG_BINS = 11;
+constexpr int QSEL_MAX_PASSES = 3;     // ceil(31 / 11)
+constexpr int QTPB = 1024;             // threads per workgroup of the histogram passes
 
-__global__ __launch_bounds__(TPB) void k_suminf(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
-                                                 int H, int32_t* __restrict__ out)
+struct QselState {
+    int32_t lo[QSEL_MAX];              // start of the quantile's window
+    long long rank[QSEL_MAX];          // 1-based rank among the values inside the window
+    unsigned int done;                 // ticket: workgroups of the running kernel that have delivered
+    int nq;
+    int W;                             // log2 of the window size; 0 = finished, lo[] are the answers
+    int shared;                        // all quantiles still share one window (first pass)
+};
+struct QselRanks { long long rank[QSEL_MAX]; int nq; };
+
+// Every workgroup calls this after its global writes; true (in all its threads) in the workgroup that arrives last.
+// Atomics on one address cost about 70 ns each when they queue up (measured: the histogram kernels slowed down by that
+// much per additional workgroup), so kernels that end in same-address atomics run with few, large workgroups.
+__device__ __forceinline__ bool last_workgroup(unsigned int* ticket)
 {
-    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (m >= n) return;
-    const int64_t a = anc ? (int64_t)anc[m] : m;
-    int32_t t = 0;
-    for (int i = 0; i < H; i++) t += src[(int64_t)(2 + i) * stride + a];
-    out[m] = t;
+    __shared__ unsigned int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u;
+    __syncthreads();
+    return s_last != 0u;
 }
 
-// histogram of the digit (v >> shift) & (bins - 1) of the values whose higher digits equal prefix[j] (pass 0: all)
-struct QselPass { unsigned int prefix[QSEL_MAX]; int nq, shift, bins, hi_shift; };
-__global__ __launch_bounds__(TPB) void k_qsel_hist(int64_t n, const int32_t* __restrict__ v, QselPass P, unsigned long long* __restrict__ hist)
+// start of a selection: called by thread 0 of the last workgroup of the kernel that produced the totals
+__device__ __forceinline__ void qsel_begin(QselState* __restrict__ st, const QselRanks& R, int32_t vmin, int32_t vmax)
+{
+    const unsigned int span = (unsigned int)(vmax - vmin);             // values are non-negative 31-bit numbers
+    int W = 0;
+    while (W < 31 && (span >> W) != 0u) W++;                           // smallest W with span < 2^W
+    for (int j = 0; j < QSEL_MAX; j++) { st->lo[j] = vmin; st->rank[j] = j < R.nq ? R.rank[j] : 1; }
+    st->nq = R.nq; st->W = W; st->shared = 1;
+}
+
+// One histogram increment per run of equal bins: neighbouring particles of a belief are alike (after resampling,
+// copies of one ancestor), so counting a run in a register and adding it once replaces most of the LDS atomics.
+struct DigitRun {
+    unsigned int digit = 0u, count = 0u;
+    __device__ __forceinline__ void add(unsigned int d, unsigned int* s_h)
+    {
+        if (d != digit && count) { atomicAdd(&s_h[digit], count); count = 0u; }
+        digit = d; count++;
+    }
+    __device__ __forceinline__ void flush(unsigned int* s_h) { if (count) atomicAdd(&s_h[digit], count); count = 0u; }
+};
+
+// One pass.  Launched QSEL_MAX_PASSES times; a pass that finds the selection finished returns at once.
+__global__ __launch_bounds__(QTPB) void k_qsel_pass(int64_t n, const int32_t* __restrict__ v, QselState* __restrict__ st,
+                                                     unsigned long long* __restrict__ hist)
 {
     __shared__ unsigned int s_h[QSEL_MAX * QSEL_BINS];
-    for (int i = threadIdx.x; i < P.nq * QSEL_BINS; i += TPB) s_h[i] = 0u;
+    __shared__ unsigned long long s_part[QTPB];
+    const int W = st->W;
+    if (W == 0) return;                                                 // uniform over the grid: no ticket is taken
+    const int nq = st->nq, shared = st->shared, nh = shared ? 1 : nq;
+    const int shift = W > QSEL_LOG_BINS ? W - QSEL_LOG_BINS : 0;
+    int32_t lo[QSEL_MAX];
+    for (int j = 0; j < QSEL_MAX; j++) lo[j] = st->lo[j];
+    for (int i = threadIdx.x; i < nh * QSEL_BINS; i += QTPB) s_h[i] = 0u;
     __syncthreads();
-    for (int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x; m < n; m += (int64_t)gridDim.x * TPB) {
-        const unsigned int x = (unsigned int)v[m];
-        const unsigned int d = (x >> P.shift) & (unsigned int)(P.bins - 1);
-        for (int j = 0; j < P.nq; j++)
-            if (P.hi_shift >= 32 || (x >> P.hi_shift) == P.prefix[j]) atomicAdd(&s_h[j * QSEL_BINS + d], 1u);
+    DigitRun run[QSEL_MAX];
+    // eight values per trip, loaded together
+    constexpr int U = 8;
+    const int64_t sweep = (int64_t)gridDim.x * QTPB * U;
+    for (int64_t base = (int64_t)blockIdx.x * QTPB * U + threadIdx.x; base < n; base += sweep) {
+        int32_t x[U];
+        bool have[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) { have[k] = base + (int64_t)k * QTPB < n; x[k] = have[k] ? v[base + (int64_t)k * QTPB] : 0; }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+#pragma unroll
+            for (int j = 0; j < QSEL_MAX; j++) {
+                if (j >= nh || !have[k]) continue;
+                const unsigned int off = (unsigned int)(x[k] - lo[j]);  // below the window: wraps to a huge number
+                if (x[k] >= lo[j] && (off >> W) == 0u) run[j].add(off >> shift, s_h + j * QSEL_BINS);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < QSEL_MAX; j++) run[j].flush(s_h + j * QSEL_BINS);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nh * QSEL_BINS; i += QTPB)
+        if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+    if (!last_workgroup(&st->done)) return;
+    // the last workgroup narrows every quantile's window to the bin that holds its rank
+    constexpr int per = QSEL_BINS / QTPB;                               // bins per thread
+    for (int j = 0; j < nq; j++) {
+        const unsigned long long* h = hist + (shared ? 0 : (size_t)j * QSEL_BINS);
+        const long long want = st->rank[j];
+        unsigned long long c[per], tot = 0ULL;
+        for (int k = 0; k < per; k++) {
+            c[k] = __hip_atomic_load(&h[threadIdx.x * per + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot += c[k];
+        }
+        // inclusive prefix sum of the threads' totals: waves by shuffles, then the wave totals through LDS
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned long long incl = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = shfl_up_u64(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        unsigned long long before = incl - tot;
+        for (int w = 0; w < wv; w++) before += s_part[w];
+        __syncthreads();
+        if ((long long)before < want && want <= (long long)(before + tot)) {          // exactly one thread
+            unsigned long long acc = before;
+            int k = 0;
+            for (; k < per - 1; k++) { if ((long long)(acc + c[k]) >= want) break; acc += c[k]; }
+            st->lo[j] = lo[shared ? 0 : j] + (int32_t)((unsigned int)(threadIdx.x * per + k) << shift);
+            st->rank[j] = want - (long long)acc;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < P.nq * QSEL_BINS; i += TPB)
-        if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+    for (int i = threadIdx.x; i < nh * QSEL_BINS; i += QTPB) hist[i] = 0ULL;
+    if (threadIdx.x == 0) { st->done = 0u; st->W = shift; st->shared = 0; }
+}
+
+// Infected total of every particle (through the ancestor index), their minimum and maximum, and the start of a
+// selection over them.  part: one (min, max) pair per workgroup.
+__global__ __launch_bounds__(TPB) void k_suminf(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
+                                                 int H, int32_t* __restrict__ out, int32_t* __restrict__ part, QselRanks R, QselState* __restrict__ st)
+{
+    __shared__ int32_t s_mm[2][TPB / 64];
+    int32_t vmin = 0x7fffffff, vmax = 0;
+    for (int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x; m < n; m += (int64_t)gridDim.x * TPB) {
+        const int64_t a = anc ? (int64_t)anc[m] : m;
+        int32_t t = 0;
+        for (int i = 0; i < H; i++) t += src[(int64_t)(2 + i) * stride + a];
+        out[m] = t;
+        vmin = t < vmin ? t : vmin; vmax = t > vmax ? t : vmax;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int32_t a = __shfl_down(vmin, d, 64), b = __shfl_down(vmax, d, 64);
+        vmin = a < vmin ? a : vmin; vmax = b > vmax ? b : vmax;
+    }
+    if ((threadIdx.x & 63) == 0) { s_mm[0][threadIdx.x >> 6] = vmin; s_mm[1][threadIdx.x >> 6] = vmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TPB / 64; w++) { vmin = s_mm[0][w] < vmin ? s_mm[0][w] : vmin; vmax = s_mm[1][w] > vmax ? s_mm[1][w] : vmax; }
+        part[2 * blockIdx.x] = vmin; part[2 * blockIdx.x + 1] = vmax;
+    }
+    if (!last_workgroup(&st->done)) return;
+    if (threadIdx.x == 0) {
+        for (unsigned int g = 0; g < gridDim.x; g++) {
+            const int32_t a = __hip_atomic_load(&part[2 * g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t b = __hip_atomic_load(&part[2 * g + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            vmin = a < vmin ? a : vmin; vmax = b > vmax ? b : vmax;
+        }
+        qsel_begin(st, R, vmin, vmax);
+        st->done = 0u;
+    }
+}
+
+// The same for the default state shape (H = 14, no pending tests: 16 rows) together with the column sums of the
+// belief mean: every row is read once, through the ancestor index, for all results.  part: per workgroup 16 column
+// sums, then minimum and maximum of the totals (18 long long); k_summary_finish adds them up.
+constexpr int SUMMARY_ROWS = 16;
+constexpr int SUMMARY_SLOT = SUMMARY_ROWS + 2;
+constexpr int SUMMARY_MAX_GROUPS = 512;
+__global__ __launch_bounds__(TPB) void k_summary16(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
+                                                    int32_t* __restrict__ out, long long* __restrict__ part, int want_quant)
+{
+    __shared__ long long s_sum[TPB / 64][SUMMARY_SLOT];
+    long long acc[SUMMARY_ROWS];
+#pragma unroll
+    for (int r = 0; r < SUMMARY_ROWS; r++) acc[r] = 0;
+    int32_t vmin = 0x7fffffff, vmax = 0;
+    // two particles per trip: their 34 loads are in flight together
+    const int64_t sweep = (int64_t)gridDim.x * TPB * 2;
+    for (int64_t base = (int64_t)blockIdx.x * TPB * 2 + threadIdx.x; base < n; base += sweep) {
+        const int64_t m0 = base, m1 = base + TPB;
+        const bool have1 = m1 < n;
+        const int64_t a0 = anc ? (int64_t)anc[m0] : m0;
+        const int64_t a1 = have1 ? (anc ? (int64_t)anc[m1] : m1) : a0;
+        int32_t v0[SUMMARY_ROWS], v1[SUMMARY_ROWS];
+#pragma unroll
+        for (int r = 0; r < SUMMARY_ROWS; r++) { v0[r] = src[(int64_t)r * stride + a0]; v1[r] = src[(int64_t)r * stride + a1]; }
+        int32_t t0 = 0, t1 = 0;
+#pragma unroll
+        for (int r = 0; r < SUMMARY_ROWS; r++) {
+            acc[r] += v0[r] + (have1 ? (long long)v1[r] : 0LL);
+            if (r >= 2) { t0 += v0[r]; t1 += v1[r]; }
+        }
+        if (want_quant) {
+            out[m0] = t0;
+            if (have1) out[m1] = t1;
+        }
+        vmin = t0 < vmin ? t0 : vmin; vmax = t0 > vmax ? t0 : vmax;
+        vmin = t1 < vmin ? t1 : vmin; vmax = t1 > vmax ? t1 : vmax;             // without m1, t1 repeats t0's particle
+    }
+    // wave, then workgroup, then this workgroup's slot
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int32_t a = __shfl_down(vmin, d, 64), b = __shfl_down(vmax, d, 64);
+        vmin = a < vmin ? a : vmin; vmax = b > vmax ? b : vmax;
+    }
+#pragma unroll
+    for (int r = 0; r < SUMMARY_ROWS; r++) {
+        unsigned long long v = (unsigned long long)acc[r];
+        for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
+        if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6][r] = (long long)v;
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6][SUMMARY_ROWS] = vmin; s_sum[threadIdx.x >> 6][SUMMARY_ROWS + 1] = vmax; }
+    __syncthreads();
+    if (threadIdx.x < SUMMARY_SLOT) {
+        long long t = s_sum[0][threadIdx.x];
+        for (int w = 1; w < TPB / 64; w++) {
+            const long long o = s_sum[w][threadIdx.x];
+            if (threadIdx.x < SUMMARY_ROWS) t += o;
+            else if (threadIdx.x == SUMMARY_ROWS) t = o < t ? o : t;
+            else t = o > t ? o : t;
+        }
+        part[(int64_t)blockIdx.x * SUMMARY_SLOT + threadIdx.x] = t;
+    }
+}
+
+// One workgroup: adds up the slots k_summary16's workgroups left (thread t takes slots t, t + 256, ..., then the 256
+// partial results are combined in thread order), adds the column sums to `sums` and starts the selection.  A kernel of
+// its own rather than a ticket in k_summary16: with hundreds of workgroups the ticket atomics alone took 30 us.
+__global__ __launch_bounds__(TPB) void k_summary_finish(int groups, const long long* __restrict__ part, long long* __restrict__ sums,
+                                                         QselRanks R, QselState* __restrict__ st, int want_quant)
+{
+    __shared__ long long s_all[TPB][SUMMARY_SLOT];
+    long long t[SUMMARY_SLOT];
+    for (int r = 0; r < SUMMARY_ROWS; r++) t[r] = 0;
+    t[SUMMARY_ROWS] = 0x7fffffff; t[SUMMARY_ROWS + 1] = 0;
+    for (int g = threadIdx.x; g < groups; g += TPB) {
+#pragma unroll
+        for (int r = 0; r < SUMMARY_SLOT; r++) {
+            const long long o = part[(int64_t)g * SUMMARY_SLOT + r];
+            if (r < SUMMARY_ROWS) t[r] += o;
+            else if (r == SUMMARY_ROWS) t[r] = o < t[r] ? o : t[r];
+            else t[r] = o > t[r] ? o : t[r];
+        }
+    }
+    for (int r = 0; r < SUMMARY_SLOT; r++) s_all[threadIdx.x][r] = t[r];
+    __syncthreads();
+    // 256 -> 8 -> 1 per column, in index order
+    constexpr int CHUNKS = 8, CHUNK = TPB / CHUNKS;
+    static_assert(CHUNKS * SUMMARY_SLOT <= TPB, "one thread per (chunk, column)");
+    const bool stage1 = threadIdx.x < CHUNKS * SUMMARY_SLOT;
+    long long u = 0;
+    if (stage1) {
+        const int r = threadIdx.x % SUMMARY_SLOT, chunk = threadIdx.x / SUMMARY_SLOT;
+        u = s_all[chunk * CHUNK][r];
+        for (int k = 1; k < CHUNK; k++) {
+            const long long o = s_all[chunk * CHUNK + k][r];
+            if (r < SUMMARY_ROWS) u += o;
+            else if (r == SUMMARY_ROWS) u = o < u ? o : u;
+            else u = o > u ? o : u;
+        }
+    }
+    __syncthreads();
+    if (stage1) s_all[threadIdx.x / SUMMARY_SLOT][threadIdx.x % SUMMARY_SLOT] = u;
+    __syncthreads();
+    if (threadIdx.x < SUMMARY_SLOT) {
+        const int r = threadIdx.x;
+        u = s_all[0][r];
+        for (int k = 1; k < CHUNKS; k++) {
+            const long long o = s_all[k][r];
+            if (r < SUMMARY_ROWS) u += o;
+            else if (r == SUMMARY_ROWS) u = o < u ? o : u;
+            else u = o > u ? o : u;
+        }
+        s_all[0][r] = u;
+        if (r < SUMMARY_ROWS) sums[r] += u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && want_quant) qsel_begin(st, R, (int32_t)s_all[0][SUMMARY_ROWS], (int32_t)s_all[0][SUMMARY_ROWS + 1]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1428,6 +1786,8 @@ int epi_ctx_create(int device, epi_ctx** out)
             HIPCHECK(hipMalloc((void**)&c->d_sums, sizeof(long long) * (2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H)));
             HIPCHECK(hipHostMalloc((void**)&c->h_pin, PIN_BYTES, hipHostMallocDefault));
             HIPCHECK(hipMalloc((void**)&c->d_small, SMALL_BYTES));
+            HIPCHECK(hipMalloc((void**)&c->d_qsel, QSEL_HIST_BYTES + 256));
+            HIPCHECK(hipMemset(c->d_qsel, 0, QSEL_HIST_BYTES + 256));
             HIPCHECK(hipEventCreate(&c->ev0));
             HIPCHECK(hipEventCreate(&c->ev1));
             return static_scratch_address(&c->d_static);
@@ -1454,6 +1814,8 @@ int epi_ctx_destroy(epi_ctx* c)
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_lf) (void)hipFree(c->d_lf);
     if (c->d_small) (void)hipFree(c->d_small);
+    if (c->d_qsel) (void)hipFree(c->d_qsel);
+    if (c->d_days) (void)hipFree(c->d_days);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1522,7 +1884,7 @@ int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief*
         HIPCHECK(hipSetDevice(c->device));
         epi_belief* b = new epi_belief();
         b->ctx = c; b->n = n_local; b->halo_cap = halo_cap;
-        b->stride = ceil_div(n_local + halo_cap, 64) * 64;          // rows start on 256-byte boundaries
+        b->stride = ceil_div(n_local + halo_cap, CTPB) * CTPB;      // rows start on 1 KB boundaries and hold whole workgroups (StepArgs::padded)
         b->n_total = n_local; b->slot0 = 0;
         b->rows = state_rows(c->P.H, c->P.D);
         b->nblocks = ceil_div(n_local, SCAN_TILE);
@@ -1530,7 +1892,7 @@ int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief*
         hipError_t e = hipMalloc((void**)&b->buf[0], bytes);
         if (e == hipSuccess) e = hipMalloc((void**)&b->buf[1], bytes);
         if (e == hipSuccess) e = hipMalloc((void**)&b->anc, sizeof(int32_t) * (size_t)n_local);
-        if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)n_local);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->lw, sizeof(double) * (size_t)(ceil_div(n_local, CTPB) * CTPB));
         if (e == hipSuccess) e = hipMalloc((void**)&b->blocksum, sizeof(unsigned long long) * (size_t)b->nblocks);
         if (e == hipSuccess) e = hipMalloc((void**)&b->blocksq, sizeof(double) * (size_t)b->nblocks);
         if (e == hipSuccess) e = hipMalloc((void**)&b->big, big_list_bytes(n_local));
@@ -1774,7 +2136,7 @@ int epi_step_batch(epi_ctx* c, epi_belief* b, const double* a, int a_per_particl
         const char* nomem = "epi_step_batch: hipMalloc failed";
         StepArgs A;
         memset(&A, 0, sizeof A);
-        A.screen = g_screen;
+        A.screen = g_screen; A.padded = 1;
         A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
         A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
         A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
@@ -1862,7 +2224,7 @@ int epi_step_injected(epi_ctx* c, epi_belief* b, const double* a, int a_per_part
         HIPCHECK(hipMemcpyAsync(dg.p, hg.data(), 8 * cnt, hipMemcpyHostToDevice, c->stream));
         StepArgs A;
         memset(&A, 0, sizeof A);
-        A.screen = g_screen;
+        A.screen = g_screen; A.padded = 1;
         A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
         A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
         A.a = a[0]; A.a_row_stride = 1; A.a_col = 0;
@@ -1913,7 +2275,7 @@ int epi_step_variates(epi_ctx* c, epi_belief* b, double a, uint64_t seed, uint32
             return fail(EPI_ENOMEM, "epi_step_variates: hipMalloc failed");
         StepArgs A;
         memset(&A, 0, sizeof A);
-        A.screen = g_screen;
+        A.screen = g_screen; A.padded = 1;
         A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
         A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
         A.a = a; A.a_row_stride = 1;
@@ -2005,7 +2367,7 @@ int epi_rollout_batch(epi_ctx* c, epi_belief* b, int T, const double* actions, i
         for (int t = 0; t < T; t++) {
             StepArgs A;
             memset(&A, 0, sizeof A);
-        A.screen = g_screen;
+        A.screen = g_screen; A.padded = 1;
             A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
             A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
             const int64_t tcol = act_per_day ? t : 0;
@@ -2057,7 +2419,7 @@ int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts
         if (n >= (1LL << 31)) return fail(EPI_ERANGE, "epi_rollout_score: n_seq * rollouts_per_seq must be < 2^31");
         HIPCHECK(hipSetDevice(c->device));
         const int rows = start->rows;
-        const int64_t stride = ceil_div(n, 64) * 64;
+        const int64_t stride = ceil_div(n, CTPB) * CTPB;
         DevBuf dact, dst[2], drew, dacc, dscore;
         const size_t sbytes = sizeof(int32_t) * (size_t)rows * (size_t)stride;
         if (dact.alloc(sizeof(double) * (size_t)n_seq * (size_t)T) != hipSuccess || dst[0].alloc(sbytes) != hipSuccess || dst[1].alloc(sbytes) != hipSuccess ||
@@ -2073,7 +2435,7 @@ int epi_rollout_score(epi_ctx* c, epi_belief* start, int64_t n_seq, int rollouts
         for (int t = 0; t < T; t++) {
             StepArgs A;
             memset(&A, 0, sizeof A);
-            A.screen = g_screen;
+            A.screen = g_screen; A.padded = 1;
             A.n = n; A.in = dst[t & 1].as<int32_t>(); A.in_stride = stride;
             A.out = dst[(t & 1) ^ 1].as<int32_t>(); A.out_stride = stride;
             A.a_dev = dact.as<double>(); A.a_row_stride = T; A.a_col = t; A.a_div = rollouts_per_seq;
@@ -2143,7 +2505,7 @@ int epi_ensemble_simulate(epi_ctx* c, epi_belief* b, int T, const double* action
         for (int t = 0; t < T; t++) {
             StepArgs A;
             memset(&A, 0, sizeof A);
-            A.screen = g_screen;
+            A.screen = g_screen; A.padded = 1;
             A.n = n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
             A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
             const int64_t tcol = act_per_day ? t : 0;
@@ -2238,16 +2600,17 @@ struct UpdateScratch {
 };
 static inline UpdateScratch own_scratch(epi_belief* b) { return UpdateScratch{b->scal, b->blocksum, b->blocksq, b->big}; }
 
-static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true)
+static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true,
+                          const int32_t* o_dev = nullptr)
 {
     StepArgs A;
     memset(&A, 0, sizeof A);
-    A.screen = g_screen;
+    A.screen = g_screen; A.padded = 1;
     A.n = b->n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
     A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
     A.a = a; A.a_row_stride = 1;
     A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0;
-    A.o = (double)o; A.lw = b->lw; A.scal = sc.scal;
+    A.o = (double)o; A.o_dev = o_dev; A.lw = b->lw; A.scal = sc.scal;
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->timing && timed) {
         HIPCHECK(hipEventCreate(&e0));
@@ -2301,9 +2664,10 @@ static int update_checks(epi_ctx* c, epi_belief* b, const char* who)
 // One whole update of a population held by one device, enqueued on the context's stream: step + weight, tile totals,
 // their scan, cumulative weights and ancestors in one pass, the long child ranges.  Five launches (six when the last
 // workgroup of the population is partial); nothing is allocated and the host does not wait.
-static int enqueue_update(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true)
+static int enqueue_update(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true,
+                          const int32_t* o_dev = nullptr)
 {
-    int rc = launch_predict(c, b, sc, a, o, seed, step, timed);
+    int rc = launch_predict(c, b, sc, a, o, seed, step, timed, o_dev);
     if (rc) return rc;
     const double u = resample_offset(seed, step);
     BigRange* list = reinterpret_cast<BigRange*>(sc.big + 2);
@@ -2328,13 +2692,20 @@ int epi_pf_update_async(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t
     });
 }
 
+// what the fixed-point weight total says about an update: every weight zero, or weights so collapsed that the
+// truncation of the fixed-point weights is no longer negligible (bound n / W above 10^-3; see include/epi.h)
+static inline uint32_t weight_flags(unsigned long long w_total, int64_t n_total)
+{
+    if (w_total == 0ULL) return EPI_F_ZERO_W;
+    return (double)n_total > 1e-3 * (double)w_total ? EPI_F_COARSE_W : 0u;
+}
+
 // diagnostics of the update whose scalars are `d`; waits for the stream, clears the flags
 static int collect_from(epi_ctx* c, epi_belief* b, DevScalars* d, double* loglik, double* ess, uint32_t* flags)
 {
     DevScalars h;
     if (int rs = read_scalars(c, d, &h)) return rs;
-    uint32_t f = h.flags;
-    if (h.w_total == 0ULL) f |= EPI_F_ZERO_W;
+    const uint32_t f = h.flags | weight_flags(h.w_total, b->n_total);
     if (flags) *flags = f;
     HIPCHECK(hipMemsetAsync(&d->flags, 0, sizeof(unsigned int), c->stream));
     const double scale = ldexp(1.0, b->frac_bits);
@@ -2669,6 +3040,18 @@ int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
 
 // ---- summaries ---------------------------------------------------------------------
 
+static int enqueue_summary(epi_ctx* c, epi_belief* b, bool want_sums, const double* q, int nq);
+
+// column sums of b added to c->d_sums (which the caller has cleared)
+static int enqueue_sums(epi_ctx* c, epi_belief* b)
+{
+    int64_t gx = ceil_div(b->n, TPB);
+    if (gx > 1024) gx = 1024;
+    k_sums<<<dim3((unsigned)gx, (unsigned)b->rows), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->d_sums);
+    HIPCHECK(hipGetLastError());
+    return EPI_OK;
+}
+
 int epi_belief_sums(epi_ctx* c, epi_belief* b, int64_t* sums)
 {
     int rc = belief_check(b, "epi_belief_sums");
@@ -2678,10 +3061,8 @@ int epi_belief_sums(epi_ctx* c, epi_belief* b, int64_t* sums)
     HIPCHECK(hipSetDevice(c->device));
     const int H = c->P.H, D = c->P.D, D1 = D + 1;
     HIPCHECK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * (size_t)b->rows, c->stream));
-    int64_t gx = ceil_div(b->n, TPB);
-    if (gx > 1024) gx = 1024;
-    k_sums<<<dim3((unsigned)gx, (unsigned)b->rows), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->d_sums);
-    HIPCHECK(hipGetLastError());
+    rc = enqueue_summary(c, b, true, nullptr, 0);
+    if (rc) return rc;
     const long long* h = reinterpret_cast<const long long*>(c->h_pin);          // rows <= 2 + H + D (H - 1): a few KB
     HIPCHECK(hipMemcpyAsync(c->h_pin, c->d_sums, sizeof(long long) * (size_t)b->rows, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
@@ -2717,6 +3098,62 @@ int epi_belief_mean(epi_ctx* c, epi_belief* b, int64_t* S, int64_t* I, int64_t* 
     return epi_mean_from_sums(&c->P, b->n, sums, S, I, R, T);
 }
 
+// 1-based rank of each quantile: the smallest value with at least ceil(q n) values <= it (rank 1 for q = 0)
+static QselRanks qsel_ranks(int64_t n, const double* q, int nq)
+{
+    QselRanks R;
+    R.nq = nq;
+    for (int j = 0; j < QSEL_MAX; j++) {
+        int64_t r = j < nq ? (int64_t)ceil(q[j] * (double)n) : 1;
+        R.rank[j] = r < 1 ? 1 : (r > n ? n : r);
+    }
+    return R;
+}
+
+// the passes of a selection over the n totals in dv (its start is already in the state)
+static int enqueue_qsel_passes(epi_ctx* c, int64_t n, const int32_t* dv)
+{
+    unsigned long long* const dh = reinterpret_cast<unsigned long long*>(c->d_qsel);
+    QselState* const st = reinterpret_cast<QselState*>(c->d_qsel + QSEL_HIST_BYTES);
+    int64_t g = ceil_div(n, (int64_t)QTPB * 16);                       // two trips of eight values per thread; few workgroups (ticket)
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    for (int pass = 0; pass < QSEL_MAX_PASSES; pass++)
+        k_qsel_pass<<<dim3((unsigned)g), dim3(QTPB), 0, c->stream>>>(n, dv, st, dh);
+    HIPCHECK(hipGetLastError());
+    return EPI_OK;
+}
+
+// Column sums (added to c->d_sums, which the caller has cleared) and / or order statistics of sum(I) of one belief,
+// enqueued; the order statistics stay in the selection state (QselState::lo).  The infected totals go where the log
+// weights of an update live (free between updates, 8 n bytes); partial results into the context's small buffer.
+static int enqueue_summary(epi_ctx* c, epi_belief* b, bool want_sums, const double* q, int nq)
+{
+    const int64_t n = b->n;
+    int32_t* const dv = reinterpret_cast<int32_t*>(b->lw);
+    QselState* const st = reinterpret_cast<QselState*>(c->d_qsel + QSEL_HIST_BYTES);
+    const QselRanks R = qsel_ranks(n, q, nq);
+    const int32_t* anc = b->has_anc ? b->anc : nullptr;
+    static_assert(sizeof(long long) * SUMMARY_SLOT * SUMMARY_MAX_GROUPS <= SMALL_BYTES, "partial results outgrew the context's small buffer");
+    if (want_sums && b->rows == SUMMARY_ROWS) {
+        int64_t gs = ceil_div(n, (int64_t)TPB * 8);
+        gs = gs < 1 ? 1 : (gs > SUMMARY_MAX_GROUPS ? SUMMARY_MAX_GROUPS : gs);
+        long long* const part = reinterpret_cast<long long*>(c->d_small);
+        k_summary16<<<dim3((unsigned)gs), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, anc, dv, part, nq > 0);
+        k_summary_finish<<<1, TPB, 0, c->stream>>>((int)gs, part, c->d_sums, R, st, nq > 0);
+    } else {
+        if (want_sums) { int rc = enqueue_sums(c, b); if (rc) return rc; }
+        if (nq) {
+            int64_t gs = ceil_div(n, (int64_t)TPB * 8);
+            gs = gs < 1 ? 1 : (gs > 256 ? 256 : gs);                      // few workgroups: the kernel ends in a ticket
+            k_suminf<<<dim3((unsigned)gs), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, anc, c->P.H, dv,
+                                                                    reinterpret_cast<int32_t*>(c->d_small), R, st);
+        }
+    }
+    HIPCHECK(hipGetLastError());
+    if (nq) return enqueue_qsel_passes(c, n, dv);
+    return EPI_OK;
+}
+
 int epi_belief_suminf_quantiles(epi_ctx* c, epi_belief* b, const double* q, int nq, int64_t* out)
 {
     int rc = belief_check(b, "epi_belief_suminf_quantiles");
@@ -2725,50 +3162,135 @@ int epi_belief_suminf_quantiles(epi_ctx* c, epi_belief* b, const double* q, int 
     if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_suminf_quantiles: a phased update is in progress");
     for (int j = 0; j < nq; j++) if (!(q[j] >= 0.0 && q[j] <= 1.0)) return fail(EPI_EINVAL, "epi_belief_suminf_quantiles: q[%d] = %g", j, q[j]);
     HIPCHECK(hipSetDevice(c->device));
-    const int64_t n = b->n;
-    // scratch: the infected totals go where the log weights of an update live (free between updates, 8 n bytes);
-    // the histograms into the context's small buffers
-    static_assert(sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS <= SMALL_BYTES && sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS <= PIN_BYTES,
-                  "histograms outgrew the context's small buffers");
-    int32_t* const dv = reinterpret_cast<int32_t*>(b->lw);
-    unsigned long long* const dh = reinterpret_cast<unsigned long long*>(c->d_small);
-    unsigned long long* const h = reinterpret_cast<unsigned long long*>(c->h_pin);
-    const size_t hist_bytes = sizeof(unsigned long long) * QSEL_MAX * QSEL_BINS;
-    k_suminf<<<dim3((unsigned)ceil_div(n, TPB)), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, b->has_anc ? b->anc : nullptr, c->P.H, dv);
-    // 1-based rank of each quantile: the smallest value with at least ceil(q n) values <= it (rank 1 for q = 0)
-    int64_t rank[QSEL_MAX];
-    for (int j = 0; j < nq; j++) {
-        int64_t r = (int64_t)ceil(q[j] * (double)n);
-        rank[j] = r < 1 ? 1 : (r > n ? n : r);
-    }
-    QselPass P;
-    memset(&P, 0, sizeof P);
-    P.nq = nq;
-    const int shifts[3] = {20, 9, 0}, bins[3] = {2048, 2048, 512};
-    int64_t gx = ceil_div(n, (int64_t)TPB * 16);
-    gx = gx < 1 ? 1 : (gx > 2048 ? 2048 : gx);
-    for (int pass = 0; pass < 3; pass++) {
-        P.shift = shifts[pass]; P.bins = bins[pass]; P.hi_shift = pass == 0 ? 32 : shifts[pass - 1];
-        HIPCHECK(hipMemsetAsync(dh, 0, hist_bytes, c->stream));
-        k_qsel_hist<<<dim3((unsigned)gx), dim3(TPB), 0, c->stream>>>(n, dv, P, dh);
-        HIPCHECK(hipGetLastError());
-        HIPCHECK(hipMemcpyAsync(h, dh, hist_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(hipStreamSynchronize(c->stream));
-        for (int j = 0; j < nq; j++) {
-            unsigned long long acc = 0;
-            int d = 0;
-            for (; d < bins[pass]; d++) {
-                const unsigned long long cnt = h[(size_t)j * QSEL_BINS + (size_t)d];
-                if (acc + cnt >= (unsigned long long)rank[j]) break;
-                acc += cnt;
-            }
-            if (d == bins[pass]) return fail(EPI_ESTATE, "epi_belief_suminf_quantiles: rank not found (internal)");
-            rank[j] -= (int64_t)acc;
-            P.prefix[j] = (pass == 0 ? 0u : (P.prefix[j] << (shifts[pass - 1] - shifts[pass]))) | (unsigned int)d;
-        }
-    }
-    for (int j = 0; j < nq; j++) out[j] = (int64_t)P.prefix[j];
+    rc = enqueue_summary(c, b, false, q, nq);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(c->h_pin, c->d_qsel + QSEL_HIST_BYTES, sizeof(QselState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const QselState* h = reinterpret_cast<const QselState*>(c->h_pin);
+    if (h->W != 0) return fail(EPI_ESTATE, "epi_belief_suminf_quantiles: selection did not finish (internal)");
+    for (int j = 0; j < nq; j++) out[j] = (int64_t)h->lo[j];
     return EPI_OK;
+}
+
+// ---- days of the closed loop, enqueued back to back --------------------------------------
+// One record per day, written by k_day_pack and read back in one copy after the last day.
+struct DayHead {
+    double r, lwmax, sumsq;
+    unsigned long long w_total;
+    int32_t o, S, sumI, R;
+    unsigned int flags, pad;
+    int32_t quant[QSEL_MAX];
+};
+static inline size_t day_rec_bytes(int rows) { return (sizeof(DayHead) + sizeof(long long) * (size_t)rows + 63) & ~(size_t)63; }
+
+// collects the day's results into its record and clears what the next day accumulates into (flags, column sums)
+__global__ __launch_bounds__(64) void k_day_pack(unsigned char* __restrict__ rec, int rows, DevScalars* __restrict__ scal_b, DevScalars* __restrict__ scal_t,
+                                                  const int32_t* __restrict__ truth, int64_t tstride, int H, const int32_t* __restrict__ o_dev,
+                                                  const double* __restrict__ r_dev, long long* __restrict__ sums, const QselState* __restrict__ st, int nq)
+{
+    DayHead* h = reinterpret_cast<DayHead*>(rec);
+    long long* tail = reinterpret_cast<long long*>(rec + sizeof(DayHead));
+    if (threadIdx.x == 0) {
+        h->r = *r_dev; h->o = *o_dev;
+        h->lwmax = scal_b->lwmax; h->sumsq = scal_b->sumsq; h->w_total = scal_b->w_total;
+        h->flags = scal_b->flags | scal_t->flags; h->pad = 0u;
+        scal_b->flags = 0u; scal_t->flags = 0u;
+        int32_t tot = 0;
+        for (int i = 0; i < H; i++) tot += truth[(int64_t)(2 + i) * tstride];
+        h->S = truth[0]; h->R = truth[tstride]; h->sumI = tot;
+        for (int j = 0; j < QSEL_MAX; j++) h->quant[j] = j < nq ? st->lo[j] : 0;
+    }
+    for (int r = threadIdx.x; r < rows; r += 64) { tail[r] = sums[r]; sums[r] = 0; }
+}
+
+int epi_closed_loop_days(epi_ctx* c, epi_belief* truth, epi_belief* b, int ndays, const double* actions, double a_prev,
+                         uint64_t seed_true, uint32_t step_true0, uint64_t seed, uint32_t step0, int nq, const double* q,
+                         int64_t* o_out, double* r_out, int64_t* true_sir, double* loglik, double* ess, uint32_t* flags,
+                         int64_t* sums, int64_t* quant)
+{
+    return guarded("epi_closed_loop_days", [&]() -> int {
+        int rc = update_checks(c, b, "epi_closed_loop_days");
+        if (rc) return rc;
+        rc = belief_check(truth, "epi_closed_loop_days");
+        if (rc) return rc;
+        if (truth->ctx != c || truth->n != 1 || truth->phase != PH_IDLE) return fail(EPI_EINVAL, "epi_closed_loop_days: the true state must be an idle population of one on the same context");
+        if (truth == b) return fail(EPI_EINVAL, "epi_closed_loop_days: the true state and the belief must be different populations");
+        if (ndays < 1 || !actions) return fail(EPI_EINVAL, "epi_closed_loop_days: ndays = %d", ndays);
+        if (nq < 0 || nq > QSEL_MAX || (nq > 0 && (!q || !quant))) return fail(EPI_EINVAL, "epi_closed_loop_days: 0 to %d quantiles", QSEL_MAX);
+        for (int j = 0; j < nq; j++) if (!(q[j] >= 0.0 && q[j] <= 1.0)) return fail(EPI_EINVAL, "epi_closed_loop_days: q[%d] = %g", j, q[j]);
+        HIPCHECK(hipSetDevice(c->device));
+        const int H = c->P.H, D = c->P.D, D1 = D + 1, rows = b->rows;
+        const size_t rec = day_rec_bytes(rows), total = rec * (size_t)ndays;
+        if (total > c->days_cap) {
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            if (c->d_days) (void)hipFree(c->d_days);
+            c->d_days = nullptr; c->days_cap = 0;
+            if (hipMalloc((void**)&c->d_days, total) != hipSuccess) return fail(EPI_ENOMEM, "epi_closed_loop_days: hipMalloc failed");
+            c->days_cap = total;
+        }
+        int32_t* const d_o = reinterpret_cast<int32_t*>(c->d_qsel + QSEL_HIST_BYTES + 128);
+        double* const d_r = reinterpret_cast<double*>(c->d_qsel + QSEL_HIST_BYTES + 136);
+        const QselState* const st = reinterpret_cast<const QselState*>(c->d_qsel + QSEL_HIST_BYTES);
+        HIPCHECK(hipMemsetAsync(c->d_sums, 0, sizeof(long long) * (size_t)rows, c->stream));
+        for (int d = 0; d < ndays; d++) {
+            // the true system's step (src/POMDPsInterface.jl:55); its observation stays on the device
+            StepArgs A;
+            memset(&A, 0, sizeof A);
+            A.screen = g_screen; A.padded = 1;
+            A.n = 1; A.in = truth->buf[truth->cur]; A.in_stride = truth->stride; A.anc = truth->has_anc ? truth->anc : nullptr;
+            A.out = truth->buf[truth->cur ^ 1]; A.out_stride = truth->stride;
+            A.a = actions[d]; A.a_row_stride = 1;
+            A.a_prev = d ? actions[d - 1] : a_prev;
+            A.seed = seed_true; A.step = step_true0 + (uint32_t)d; A.slot0 = (uint64_t)truth->slot0; A.scal = truth->scal;
+            A.o_out = d_o; A.r_out = d_r;
+            HIPCHECK(launch_step<false>(c, A));
+            truth->cur ^= 1; truth->has_anc = false;
+            // the belief update on that observation (src/POMDPsInterface.jl:56)
+            rc = enqueue_update(c, b, own_scratch(b), actions[d], 0, seed, step0 + (uint32_t)d, true, d_o);
+            if (rc) return rc;
+            // what a plot of the belief history needs of the posterior (src/plots.jl:47)
+            rc = enqueue_summary(c, b, sums != nullptr, q, nq);
+            if (rc) return rc;
+            k_day_pack<<<1, 64, 0, c->stream>>>(c->d_days + rec * (size_t)d, rows, b->scal, truth->scal, truth->buf[truth->cur], truth->stride, H,
+                                                d_o, d_r, c->d_sums, st, nq);
+            HIPCHECK(hipGetLastError());
+        }
+        std::vector<unsigned char> hv;
+        const unsigned char* h;
+        if (total <= PIN_BYTES) {
+            HIPCHECK(hipMemcpyAsync(c->h_pin, c->d_days, total, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            h = c->h_pin;
+        } else {
+            hv.resize(total);
+            HIPCHECK(hipMemcpyAsync(hv.data(), c->d_days, total, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(hipStreamSynchronize(c->stream));
+            h = hv.data();
+        }
+        const double scale = ldexp(1.0, b->frac_bits);
+        const int ns = 2 + H + D1 * H;
+        for (int d = 0; d < ndays; d++) {
+            const DayHead* e = reinterpret_cast<const DayHead*>(h + rec * (size_t)d);
+            const long long* tail = reinterpret_cast<const long long*>(h + rec * (size_t)d + sizeof(DayHead));
+            if (o_out) o_out[d] = e->o;
+            if (r_out) r_out[d] = e->r;
+            if (true_sir) { true_sir[3 * d] = e->S; true_sir[3 * d + 1] = e->sumI; true_sir[3 * d + 2] = e->R; }
+            if (loglik) loglik[d] = e->w_total ? e->lwmax + log((double)e->w_total / scale / (double)b->n_total) - 0.91893853320467274178 : -INFINITY;
+            if (ess) ess[d] = e->sumsq > 0.0 ? ((double)e->w_total * (double)e->w_total) / e->sumsq : 0.0;
+            if (flags) flags[d] = e->flags | weight_flags(e->w_total, b->n_total);
+            if (quant) for (int j = 0; j < nq; j++) quant[(size_t)d * nq + j] = e->quant[j];
+            if (sums) {
+                int64_t* sd = sums + (size_t)d * ns;
+                sd[0] = tail[0]; sd[1] = tail[1];
+                for (int i = 0; i < H; i++) sd[2 + i] = tail[2 + i];
+                int64_t* ts = sd + 2 + H;
+                for (int j = 0; j < D1 * H; j++) ts[j] = 0;
+                for (int cidx = 1; cidx < H; cidx++)
+                    for (int r = 0; r < D; r++) ts[cidx * D1 + r] = tail[tests_row(H, r, cidx)];
+            }
+        }
+        return EPI_OK;
+    });
 }
 
 int epi_belief_sample(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr, int64_t* S, int64_t* I, int64_t* R, int64_t* T)

@@ -277,6 +277,8 @@ class ShardedFilter:
         W = sum(w_shard)
         if W == 0:
             flags |= _lib.EPI_F_ZERO_W
+        elif self.n_total > _lib.COARSE_W_BOUND * W:
+            flags |= _lib.EPI_F_COARSE_W
         self.step += 1
         loglik = (lwmax + math.log(W / 2.0 ** self.frac_bits / self.n_total) - 0.5 * math.log(2 * math.pi)) if W else float("-inf")
         return {"loglik": loglik, "ess": (float(W) ** 2 / sumsq) if sumsq > 0 else 0.0, "flags": flags,

@@ -457,11 +457,55 @@ def SimulateEnsemble(T: int, trajectories: int, params: CovidPOMDP, action, seed
     return np.ascontiguousarray(np.transpose(hist[:, :, :3], (2, 1, 0)))
 
 
+def _mean_from_sums(ctx: Context, n_total: int, sums: np.ndarray, prev_action) -> State:
+    """mean(pc, pomdp) (src/updater.jl:5-25) from the integer column sums of a belief."""
+    p = ctx.pomdp
+    H, D1 = p.horizon, p.test_delay + 1
+    S, R = C.c_int64(), C.c_int64()
+    I = np.empty(H, dtype=np.int64)
+    T = np.empty((H, D1), dtype=np.int64)
+    sums = np.ascontiguousarray(sums, dtype=np.int64)
+    check(ctx.lib.epi_mean_from_sums(C.byref(ctx._cparams), int(n_total), as_i64p(sums), C.byref(S), as_i64p(I), C.byref(R), as_i64p(T)))
+    return State(S.value, I, R.value, T.T.copy(), prev_action)
+
+
+def closed_loop_days(true: ParticleCollection, b: ParticleCollection, upd: BootstrapFilter, actions, seed_true: int, step_true0: int,
+                     q=None, want_sums: bool = False) -> dict:
+    """len(actions) consecutive days of the closed loop (src/POMDPsInterface.jl:41-60) in one call: per day the true
+    system `true` (a collection of one particle on b's context) steps, b is updated on that step's observation and
+    the posterior is summarised, all enqueued on the device with one host wait at the end.  Advances upd.step.
+    Returns per-day arrays: o, r, true_sir[., 3] (S, sum I, R of the true state after the step), loglik, ess, flags
+    and, if asked for, sums (column sums of the posterior) and quant (order statistics q of sum(I))."""
+    if true.ctx is not b.ctx or true.n != 1:
+        raise ValueError("the true state must be a collection of one particle on the belief's context")
+    if b.n != upd.n:
+        raise ValueError("belief size differs from the filter's particle count")
+    acts = np.ascontiguousarray(np.atleast_1d(np.asarray(actions, dtype=np.float64)))
+    k = acts.size
+    p = b.ctx.pomdp
+    ns = 2 + p.horizon + (p.test_delay + 1) * p.horizon
+    qs = None if q is None else np.ascontiguousarray(np.atleast_1d(np.asarray(q, dtype=np.float64)))
+    nq = 0 if qs is None else qs.size
+    out = {"o": np.empty(k, dtype=np.int64), "r": np.empty(k), "true_sir": np.empty((k, 3), dtype=np.int64),
+           "loglik": np.empty(k), "ess": np.empty(k), "flags": np.empty(k, dtype=np.uint32),
+           "sums": np.empty((k, ns), dtype=np.int64) if want_sums else None,
+           "quant": np.empty((k, nq), dtype=np.int64) if nq else None}
+    check(b.ctx.lib.epi_closed_loop_days(
+        b.ctx.handle, true.handle, b.handle, k, as_f64p(acts), _prev_prop(true), seed_true, step_true0, upd.seed, upd.step,
+        nq, as_f64p(qs), as_i64p(out["o"]), as_f64p(out["r"]), as_i64p(out["true_sir"]), as_f64p(out["loglik"]), as_f64p(out["ess"]),
+        out["flags"].ctypes.data_as(C.POINTER(C.c_uint32)), as_i64p(out["sums"]), as_i64p(out["quant"])))
+    upd.step += k
+    upd.last_loglik, upd.last_ess, upd.last_flags = float(out["loglik"][-1]), float(out["ess"][-1]), int(out["flags"][-1])
+    true.prev_action = b.prev_action = Action(float(acts[-1]))
+    return out
+
+
 def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: CovidPOMDP,
                        planner: Callable[[ParticleCollection], Action], seed: int = _DEFAULT_SEED,
                        keep_beliefs: bool = False) -> SimHist:
     """Simulate(T, state, b, pomdp, planner) (src/POMDPsInterface.jl:29-62):
-    plan every test_period days, step the true state, update the belief.
+    plan every test_period days, step the true state, update the belief.  The days between two planner calls run as
+    one device call (closed_loop_days).
     keep_beliefs: False, True (a copy of every day's belief, as the reference keeps) or "summary" (per day the
     mean state and the 5 / 50 / 95 % order statistics of sum(I), reduced on the device)."""
     single = unity_test_period(pomdp)
@@ -471,19 +515,32 @@ def SimulateClosedLoop(T: int, state: State, b: ParticleCollection, pomdp: Covid
     rewards = np.zeros(T)
     actions: List[Action] = []
     beliefs = []
-    true = ParticleCollection.from_states(single, [state], b.ctx.device)   # the true state stays on the device too
-    for day in range(T):
-        action = planner(b) if day % pomdp.test_period == 0 else actions[day - 1]
-        sus[day], inf[day], rec[day] = state.S, int(state.I.sum()), state.R
-        actions.append(action)
-        if keep_beliefs == "summary":
-            qs = np.array([0.05, 0.5, 0.95])
-            beliefs.append(BeliefSummary(mean(b), qs, suminf_quantiles(b, qs)))
-        elif keep_beliefs:
+    summary = isinstance(keep_beliefs, str) and keep_beliefs == "summary"
+    copies = keep_beliefs is True
+    qs = np.array([0.05, 0.5, 0.95])
+    period = max(1, pomdp.test_period)
+    true = ParticleCollection(b.ctx, 1)                          # the true state lives on the device too
+    true.upload(*_flatten_states(single, [state]))
+    true.prev_action = state.prev_action
+    cur = (state.S, int(state.I.sum()), state.R)
+    prior = BeliefSummary(mean(b), qs, suminf_quantiles(b, qs)) if summary else None
+    day, action = 0, None
+    while day < T:
+        if day % period == 0:
+            action = planner(b)
+        k = 1 if copies else min(period - day % period, T - day)
+        if copies:
             beliefs.append(b.copy())
-        o, r = _gen_in_place(single, true, action, seed ^ 0x7275E, day)
-        state = true.particles[0]
-        b = update(upd, b, action, o)
-        rewards[day], tests[day] = r, o
+        res = closed_loop_days(true, b, upd, [action.testing_prop] * k, seed ^ 0x7275E, day, q=qs if summary else None, want_sums=summary)
+        for j in range(k):
+            d = day + j
+            sus[d], inf[d], rec[d] = cur
+            cur = tuple(int(v) for v in res["true_sir"][j])
+            actions.append(action)
+            rewards[d], tests[d] = res["r"][j], res["o"][j]
+            if summary:
+                beliefs.append(prior)
+                prior = BeliefSummary(_mean_from_sums(b.ctx, b.n, res["sums"][j], action), qs, res["quant"][j].copy())
+        day += k
     true.close()
     return SimHist(sus, inf, rec, pomdp.N, T, tests, actions, rewards, beliefs)

@@ -52,6 +52,7 @@ extern "C" {
 #define EPI_F_NEG_NT     2u /* a tested count was negative                          */
 #define EPI_F_BAD_DENOM  4u /* N - R <= 0 in incident_infections (simulate.jl:42)   */
 #define EPI_F_ZERO_W     8u /* every particle weight was zero: particles kept       */
+#define EPI_F_COARSE_W  16u /* the fixed-point weights were coarse for this update (see below) */
 /* Degenerate weights, where this library and ParticleFilters.jl differ (the reference's own behaviour there is NaN
  * arithmetic, not a specification):
  *   - Normal(mu, 0) (no one tested, or every test probability 0 or 1): a particle whose mu equals o gets weight 1
@@ -59,6 +60,12 @@ extern "C" {
  *     the reference's pdf is Inf / 0 there.
  *   - every weight zero: the particles are kept in place and EPI_F_ZERO_W is raised; the reference's low-variance
  *     resampler would return n copies of its first particle (its cumulative-weight walk never advances).
+ * Resampling works on fixed-point weights floor(w_i / w_max 2^F) with F = 53 - ceil(log2 n) fractional bits (at most
+ * 40), so that the sum over the population is exact in 53 bits whatever the order (and hence the number of shards).
+ * A particle lighter than 2^-F w_max gets no offspring, and all truncations together remove at most n 2^-F w_max of
+ * the weight; against the total, at most n / W (W = the fixed-point total).  That is below 10^-4 for every update of
+ * up to 10^6 particles and for any size while the weights are spread; it grows when 10^7 or more particles collapse
+ * onto a few (n = 10^8, F = 26: about 1.5 / (sum of w_i / w_max)).  EPI_F_COARSE_W reports n / W > 10^-3.
  * The samplers cap a rejection draw at 512 attempts (probability of reaching it below 10^-400 for any admissible
  * parameters); a draw that exhausted them would differ between the two step kernels. */
 
@@ -280,6 +287,29 @@ int epi_belief_suminf_quantiles(epi_ctx *ctx, epi_belief *b, const double *q, in
  * samples states from the belief). */
 int epi_belief_sample(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr,
                       int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+
+/* ---- the closed loop, several days per call -------------------------------------- */
+
+/* `ndays` consecutive days of the closed loop of src/POMDPsInterface.jl:41-60 after the planner has chosen their
+ * actions (the reference plans every test_period days and repeats the action in between, :43-47): per day the
+ * true system steps (POMDPs.gen on the unit-period model, :55), the belief is updated on that step's observation
+ * (:56), and what a plot of the belief history needs of the posterior (src/plots.jl:47; the reference keeps whole
+ * ParticleCollections, :53) is reduced on the device.  Everything is enqueued back to back -- the observation goes
+ * from the true step to the update in device memory -- and the host waits once, after the last day.
+ *   truth    a population of ONE particle on the same context: the true state (advanced ndays days)
+ *   b        the belief, a whole population (advanced by ndays updates)
+ *   actions  ndays testing proportions; a_prev: the action of the day before the first
+ *   true system draws: streams (seed_true, step_true0 + d); filter: (seed, step0 + d)
+ * Outputs, each optional (NULL), per day d:
+ *   o[d], r[d]      sum(pos_tests) and reward of the true step (src/simulate.jl:160-166)
+ *   true_sir[3 d..] S, sum(I), R of the true state AFTER the day's step
+ *   loglik[d], ess[d], flags[d]   as epi_pf_update returns them (flags also carry those of the true step)
+ *   sums[d (2 + H + (D+1) H) ..]  column sums of the posterior as epi_belief_sums returns them
+ *   quant[d nq ..]  order statistics q[0..nq) of sum(I) over the posterior as epi_belief_suminf_quantiles (nq <= 4) */
+int epi_closed_loop_days(epi_ctx *ctx, epi_belief *truth, epi_belief *b, int ndays, const double *actions, double a_prev,
+                         uint64_t seed_true, uint32_t step_true0, uint64_t seed, uint32_t step0, int nq, const double *q,
+                         int64_t *o, double *r, int64_t *true_sir, double *loglik, double *ess, uint32_t *flags,
+                         int64_t *sums, int64_t *quant);
 
 /* ---- for callers that cannot allocate ------------------------------------------- */
 /* epi_pf_update for hosts that must not call hipMalloc while they run (code under HIP graph capture, tight

@@ -72,6 +72,7 @@ typedef struct {
 #define ORC_F_NEG_NT     2u   /* tested count negative                        */
 #define ORC_F_BAD_DENOM  4u   /* N - R <= 0 in incident_infections            */
 #define ORC_F_ZERO_W     8u   /* all weights zero in the filter update        */
+#define ORC_F_COARSE_W 16u
 
 /* ------------------------------------------------------------------ */
 /* bit casts                                                           */
@@ -787,6 +788,7 @@ uint32_t orc_pf_update(const orc_params *P, int64_t n,
         uint64_t W = orc_cumsum(n, wq, 0, wq);
         double u = orc_resample_u(seed, step);
         orc_ancestors(n, wq, W, u, 0, n, anc);
+        if ((double)n > 1e-3 * (double)W) flags |= ORC_F_COARSE_W;   /* truncation bound n / W of the fixed-point weights */
         if (W_out) *W_out = W;
         if (ess_out) *ess_out = ((double)W * (double)W) / s2;
     }

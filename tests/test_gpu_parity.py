@@ -263,6 +263,47 @@ def test_pf_closed_loop_bit_exact(delay):
         assert (m.S, m.R) == (eS, eR) and (m.I == eI).all() and (m.Tests == eT.T).all()
 
 
+@pytest.mark.parametrize("delay", [0, 1])
+def test_closed_loop_days_bit_exact(delay):
+    """Several days of the closed loop per device call (true step, update on its observation handed over in device
+    memory, posterior sums and order statistics) against the oracle taken day by day: observations, rewards, the
+    true state, diagnostics, every posterior particle, the column sums and the order statistics."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 5000
+    st = orc.init_normal(n, 8_000.0, 4_000.0, SEED + delay)
+    tr = orc.init_normal(1, 8_000.0, 4_000.0, 777)
+    b = _belief(pomdp, st)
+    true = _belief(pomdp, tr)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    qs = np.array([0.05, 0.5, 0.95, 1.0])
+    acts = [0.3, 0.3, 0.1, 0.4, 0.4]
+    day, a_prev = 0, 0.0
+    for chunk in (acts[:2], acts[2:]):                        # two calls: the second starts from a pending ancestor index
+        res = em.interface.closed_loop_days(true, b, upd, chunk, 555, day, q=qs, want_sums=True)
+        for j, a in enumerate(chunk):
+            tr, o, r, _, fl = orc.step_batch(tr, a, a_prev=a_prev, seed=555, step=day)
+            st, info = orc.pf_update(st, a, int(o[0]), SEED, day)
+            assert res["o"][j] == o[0] and res["r"][j] == r[0]
+            assert tuple(res["true_sir"][j]) == (tr[0][0], tr[1][0].sum(), tr[2][0])
+            assert res["flags"][j] == (info["flags"] | fl)
+            assert abs(res["ess"][j] - info["ess"]) <= 1e-9 * info["ess"]
+            ll = info["lwmax"] + np.log(info["W"] / 2.0 ** pyoracle.lib().orc_frac_bits(n) / n) - 0.5 * np.log(2 * np.pi)
+            assert abs(res["loglik"][j] - ll) <= 1e-9 * max(1.0, abs(ll))
+            H = pomdp.horizon
+            assert res["sums"][j][0] == st[0].sum() and res["sums"][j][1] == st[2].sum()
+            assert (res["sums"][j][2:2 + H] == st[1].sum(axis=0)).all()
+            assert (res["sums"][j][2 + H:].reshape(H, delay + 1) == st[3].sum(axis=0)).all()
+            tot = np.sort(st[1].sum(axis=1))
+            ranks = np.clip(np.ceil(qs * n).astype(np.int64), 1, n)
+            assert (res["quant"][j] == tot[ranks - 1]).all()
+            a_prev = a
+            day += 1
+        _eq(b.download(), st)
+        _eq(true.download(), tr)
+    assert upd.step == len(acts)
+
+
 def test_pf_million_particles_bit_exact():
     """Three successive updates of 10^6 particles against the oracle: every posterior particle, ancestor
     concentration included (the second and third updates resample a belief that already holds duplicates)."""
@@ -727,6 +768,25 @@ def test_config2_closed_loop_million_particles_50_days():
     assert (h2.inf == h.inf).all() and (h2.pos_test == h.pos_test).all()
     S2, I2, R2, _ = b2.download()
     assert (S2 == S).all() and (I2 == I).all() and (R2 == R).all()
+
+
+def test_coarse_weight_flag_when_a_large_population_collapses():
+    """3 10^7 particles carry 28 fractional weight bits.  An ordinary observation leaves the truncation bound n / W far
+    below 10^-3; one far in the tail puts nearly all weight on a handful of particles, the bound passes 10^-3 and the
+    update says so (EPI_F_COARSE_W) while still producing a valid posterior."""
+    pomdp = em.make_pomdp()
+    n = 30_000_000
+    b = em.initialbelief(pomdp, n, seed=SEED)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    em.update(upd, b, em.Action(0.2), 12_000)
+    assert upd.last_flags == 0 and upd.last_ess > 1e5
+    em.update(upd, b, em.Action(0.2), 60_000)
+    assert upd.last_flags == _lib.EPI_F_COARSE_W, upd.last_flags
+    assert 1.0 <= upd.last_ess < 1e4
+    sums = np.zeros(2 + 14 + 14, dtype=np.int64)
+    check(b.ctx.lib.epi_belief_sums(b.ctx.handle, b.handle, as_i64p(sums)))
+    assert sums[:16].sum() == n * pomdp.N and (sums >= 0).all()
+    b.close()
 
 
 def test_config4_scenario_scoring_full_size():

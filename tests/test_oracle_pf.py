@@ -71,6 +71,56 @@ def test_systematic_resampling_equals_sequential_walk():
     assert 0.0 <= pyoracle.lib().orc_resample_u(1, 2) < 1.0
 
 
+def _fp64_low_variance_walk(w, u):
+    """ParticleFilters.jl's LowVarianceResampler on binary64 weights, without any quantisation: step = sum(w) / n,
+    slot m takes the first particle whose running sum c_i (accumulated in index order, as `c += w[i]` does) reaches
+    U_m = (m + u) step."""
+    n = w.size
+    c = np.cumsum(w)                                  # sequential accumulation in index order
+    U = (np.arange(n) + u) * (c[-1] / n)
+    return np.minimum(np.searchsorted(c, U, side="left"), n - 1)
+
+
+def test_fixed_point_resampler_against_the_fp64_walk_when_the_weights_collapse():
+    """10^6 particles whose weight sits on a few dozen of them (ESS < 100): the offspring counts of the fixed-point
+    resampler against those of the sequential binary64 walk of the reference's resampler, for the library's number of
+    fractional bits at this size (33) and for 19 bits, which puts 10^6 particles where 10^8 are at their 26 bits
+    (n 2^-F = 1.9).  The truncation bound n / W is what the library reports as EPI_F_COARSE_W above 10^-3."""
+    L = pyoracle.lib()
+    rng = np.random.default_rng(12)
+    n = 1_000_000
+    lw = -0.5 * (rng.normal(0.0, 1.0, n) * 3e4) ** 2               # log weights: a needle, ESS of a few dozen
+    lw[rng.integers(0, n)] = 0.0
+    w = np.exp(lw - lw.max())
+    ess = w.sum() ** 2 / (w * w).sum()
+    assert ess < 100
+    u = L.orc_resample_u(5, 2)
+    want = np.bincount(_fp64_low_variance_walk(w, u), minlength=n)
+    for F, coarse in ((L.orc_frac_bits(n), False), (19, True)):
+        wq = np.empty(n, np.uint64)
+        L.orc_quantize(n, lw.ctypes.data_as(_f64p), float(lw.max()), F, wq.ctypes.data_as(_u64p))
+        Cc = np.empty(n, np.uint64)
+        W = L.orc_cumsum(n, wq.ctypes.data_as(_u64p), 0, Cc.ctypes.data_as(_u64p))
+        anc = np.empty(n, np.int64)
+        L.orc_ancestors(n, Cc.ctypes.data_as(_u64p), W, u, 0, n, anc.ctypes.data_as(_i64p))
+        got = np.bincount(anc, minlength=n)
+        bound = n / float(W)                                       # relative weight the truncation can remove
+        assert (bound > 1e-3) == coarse
+        # weight actually lost to truncation, relative to the total
+        lost = 1.0 - float(W) / (w.sum() * 2.0 ** F)
+        assert 0.0 <= lost <= bound
+        # offspring counts: every particle within one child of n w_i / sum(w) in both, so they differ by the lost share
+        l1 = np.abs(got - want).sum() / n
+        assert l1 <= 2.0 * lost + 4.0 * np.count_nonzero(want) / n, (F, l1, lost)
+        heavy = np.argsort(w)[-10:]
+        assert (np.abs(got[heavy] - want[heavy]) <= 1 + 2.0 * lost * want[heavy]).all()
+        # first two moments of the offspring counts
+        assert got.sum() == n == want.sum()
+        assert abs((got.astype(float) ** 2).sum() - (want.astype(float) ** 2).sum()) <= (4.0 * lost + 1e-4) * (want.astype(float) ** 2).sum()
+        if not coarse:
+            assert l1 < 1e-3
+
+
 def test_belief_mean_rounds_half_even():
     pomdp = make_pomdp(LOD=5, test_delay=2)
     orc = pyoracle.Oracle(pomdp.to_c())
