@@ -85,6 +85,16 @@ SIGNATURES = {
     "epi_pf_update_noalloc": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p]),
     "epi_closed_loop_days": (C.c_int, [_vp, _vp, _vp, C.c_int, _f64p, C.c_double, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
                                        C.c_int, _f64p, _i64p, _f64p, _i64p, _f64p, _f64p, _u32p, _i64p, _i64p]),
+    "epi_mctx_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(epi_params), C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "epi_mctx_destroy": (C.c_int, [_vp]),
+    "epi_mctx_shards": (C.c_int, [_vp]),
+    "epi_mctx_size": (C.c_int64, [_vp]),
+    "epi_mctx_init_normal": (C.c_int, [_vp, C.c_double, C.c_double, C.c_uint64]),
+    "epi_mctx_upload": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "epi_mctx_download": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "epi_mpf_update": (C.c_int, [_vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p, _i64p]),
+    "epi_mctx_sums": (C.c_int, [_vp, _i64p]),
+    "epi_mctx_mean": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "epi_pf_frac_bits": (C.c_int, [C.c_int64]),
     "epi_pf_predict": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p]),
     "epi_pf_weigh": (C.c_int, [_vp, _vp, C.c_double, _u64p, _f64p, _u32p]),

@@ -32,6 +32,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is looked up at run time, when a caller asks for it
 #include <new>
 #include <string>
 #include <vector>
@@ -3319,6 +3321,323 @@ int epi_belief_sample(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr, in
             for (int cidx = 1; cidx < H; cidx++)
                 for (int r = 0; r < D; r++) T[cidx * D1 + r] = h[(size_t)tests_row(H, r, cidx)];
         }
+        return EPI_OK;
+    });
+}
+
+// ---- one population sharded over several devices, driven by one host thread ------------------------
+// epi_mctx holds G shards (an epi_ctx and an epi_belief each, shard g = global slots [n g / G, n (g + 1) / G)) and runs
+// the phased update over them: the host never waits between the phases of one shard, only once per update for the
+// weight totals that the resampling plan needs.  Particles that change shard go device to device
+// (hipMemcpyPeerAsync) in packed blocks; the two small exchanges (maximum log weight, then four doubles per shard)
+// go either through page-locked host memory or through RCCL (ncclAllReduce / ncclAllGather inside one group call),
+// which is looked up at run time so that the library has no link-time dependency on it.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static int rccl_load(RcclApi& R)
+{
+    R.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!R.handle) R.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!R.handle) return fail(EPI_EINVAL, "epi_mctx_create: RCCL asked for but librccl.so cannot be loaded: %s", dlerror());
+    R.CommInitAll = reinterpret_cast<decltype(R.CommInitAll)>(dlsym(R.handle, "ncclCommInitAll"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.handle, "ncclCommDestroy"));
+    R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(dlsym(R.handle, "ncclAllReduce"));
+    R.AllGather = reinterpret_cast<decltype(R.AllGather)>(dlsym(R.handle, "ncclAllGather"));
+    R.GroupStart = reinterpret_cast<decltype(R.GroupStart)>(dlsym(R.handle, "ncclGroupStart"));
+    R.GroupEnd = reinterpret_cast<decltype(R.GroupEnd)>(dlsym(R.handle, "ncclGroupEnd"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.handle, "ncclGetErrorString"));
+    if (!R.CommInitAll || !R.CommDestroy || !R.AllReduce || !R.AllGather || !R.GroupStart || !R.GroupEnd || !R.GetErrorString)
+        return fail(EPI_EINVAL, "epi_mctx_create: librccl.so lacks an entry point this library uses");
+    return EPI_OK;
+}
+
+struct epi_mctx {
+    int G = 0;
+    int64_t n_total = 0;
+    epi_params P;
+    std::vector<int> device;
+    std::vector<epi_ctx*> ctx;
+    std::vector<epi_belief*> b;
+    std::vector<int64_t> start;             // G + 1 shard boundaries
+    std::vector<double*> d_x;               // per shard, on its device: [0] local max, [1] global max, [2..6) totals, [8 .. 8 + 4 G) all totals
+    std::vector<int32_t*> d_send, d_recv;   // per shard: packed blocks leaving / arriving (rows x n_local int32 each)
+    std::vector<hipEvent_t> ev;             // per shard: its outgoing copies are complete
+    double* h_x = nullptr;                  // page-locked: 8 doubles per shard
+    bool rccl = false;
+    RcclApi api;
+    std::vector<ncclComm_t> comm;
+    int64_t moved = 0;                      // particles that changed shard in the last update
+};
+
+#define NCCLCHECK(m, expr)                                                                                  \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return fail(EPI_EHIP, "%s failed: %s", #expr, (m)->api.GetErrorString(r_));   \
+    } while (0)
+
+int epi_mctx_destroy(epi_mctx* m)
+{
+    if (!m) return EPI_OK;
+    for (int g = 0; g < (int)m->ctx.size(); g++) {
+        if (m->ctx[g]) { (void)hipSetDevice(m->device[g]); (void)hipStreamSynchronize(m->ctx[g]->stream); }
+    }
+    for (size_t g = 0; g < m->comm.size(); g++) if (m->comm[g]) (void)m->api.CommDestroy(m->comm[g]);
+    for (int g = 0; g < (int)m->ctx.size(); g++) {
+        if (!m->ctx[g]) continue;                               // creation stopped before this shard (its device may not even exist)
+        (void)hipSetDevice(m->device[g]);
+        if (g < (int)m->ev.size() && m->ev[g]) (void)hipEventDestroy(m->ev[g]);
+        if (g < (int)m->d_x.size() && m->d_x[g]) (void)hipFree(m->d_x[g]);
+        if (g < (int)m->d_send.size() && m->d_send[g]) (void)hipFree(m->d_send[g]);
+        if (g < (int)m->d_recv.size() && m->d_recv[g]) (void)hipFree(m->d_recv[g]);
+        if (g < (int)m->b.size() && m->b[g]) (void)epi_belief_destroy(m->b[g]);
+        if (m->ctx[g]) (void)epi_ctx_destroy(m->ctx[g]);
+    }
+    if (m->h_x) (void)hipHostFree(m->h_x);
+    if (m->api.handle) (void)dlclose(m->api.handle);
+    delete m;
+    return EPI_OK;
+}
+
+int epi_mctx_create(const int* device_ids, int n_shards, const epi_params* p, int64_t n_total, int use_rccl, epi_mctx** out)
+{
+    return guarded("epi_mctx_create", [&]() -> int {
+        if (!device_ids || !p || !out || n_shards < 1 || n_shards > 64) return fail(EPI_EINVAL, "epi_mctx_create: bad argument (1 to 64 shards)");
+        if (n_total < n_shards) return fail(EPI_EINVAL, "epi_mctx_create: fewer particles than shards");
+        if (use_rccl)
+            for (int g = 0; g < n_shards; g++)
+                for (int h = 0; h < g; h++)
+                    if (device_ids[g] == device_ids[h]) return fail(EPI_EINVAL, "epi_mctx_create: RCCL needs one device per shard (device %d is named twice)", device_ids[g]);
+        epi_mctx* m = new epi_mctx();
+        struct Owner { epi_mctx* m; ~Owner() { if (m) epi_mctx_destroy(m); } } owner{m};
+        const int G = n_shards;
+        m->G = G; m->n_total = n_total; m->P = *p; m->rccl = use_rccl != 0;
+        m->device.assign(device_ids, device_ids + G);
+        m->ctx.assign(G, nullptr); m->b.assign(G, nullptr); m->d_x.assign(G, nullptr); m->d_send.assign(G, nullptr); m->d_recv.assign(G, nullptr);
+        m->ev.assign(G, nullptr);
+        m->start.resize(G + 1);
+        for (int g = 0; g <= G; g++) m->start[g] = shard_start(n_total, G, g);
+        const int rows = state_rows(p->H, p->D);
+        for (int g = 0; g < G; g++) {
+            int rc = epi_ctx_create(device_ids[g], &m->ctx[g]);
+            if (rc) return rc;
+            rc = epi_params_set(m->ctx[g], p);
+            if (rc) return rc;
+            m->ctx[g]->external = true;                         // the phases of an update only enqueue; the host waits where this code says so
+            const int64_t nl = m->start[g + 1] - m->start[g];
+            rc = epi_belief_create(m->ctx[g], nl, G > 1 ? nl : 0, &m->b[g]);
+            if (rc) return rc;
+            rc = epi_belief_set_shard(m->b[g], n_total, m->start[g]);
+            if (rc) return rc;
+            HIPCHECK(hipSetDevice(device_ids[g]));
+            HIPCHECK(hipMalloc((void**)&m->d_x[g], sizeof(double) * (size_t)(8 + 4 * G)));
+            HIPCHECK(hipMemset(m->d_x[g], 0, sizeof(double) * (size_t)(8 + 4 * G)));
+            if (G > 1) {
+                HIPCHECK(hipMalloc((void**)&m->d_send[g], sizeof(int32_t) * (size_t)rows * (size_t)nl));
+                HIPCHECK(hipMalloc((void**)&m->d_recv[g], sizeof(int32_t) * (size_t)rows * (size_t)nl));
+            }
+            HIPCHECK(hipEventCreateWithFlags(&m->ev[g], hipEventDisableTiming));
+            for (int h = 0; h < g; h++) {                       // direct copies between the two devices where the hardware allows
+                if (device_ids[h] == device_ids[g]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, device_ids[g], device_ids[h]) == hipSuccess && can) {
+                    (void)hipSetDevice(device_ids[g]); (void)hipDeviceEnablePeerAccess(device_ids[h], 0);
+                    (void)hipSetDevice(device_ids[h]); (void)hipDeviceEnablePeerAccess(device_ids[g], 0);
+                    (void)hipGetLastError();                    // "already enabled" is not an error here
+                }
+            }
+        }
+        HIPCHECK(hipHostMalloc((void**)&m->h_x, sizeof(double) * 8 * (size_t)G, hipHostMallocDefault));
+        if (m->rccl) {
+            int rc = rccl_load(m->api);
+            if (rc) return rc;
+            m->comm.assign(G, nullptr);
+            NCCLCHECK(m, m->api.CommInitAll(m->comm.data(), G, device_ids));
+        }
+        owner.m = nullptr;
+        *out = m;
+        return EPI_OK;
+    });
+}
+
+int epi_mctx_shards(const epi_mctx* m) { return m ? m->G : 0; }
+int64_t epi_mctx_size(const epi_mctx* m) { return m ? m->n_total : 0; }
+
+int epi_mctx_init_normal(epi_mctx* m, double mu, double sigma, uint64_t seed)
+{
+    if (!m) return fail(EPI_EINVAL, "epi_mctx_init_normal: NULL");
+    for (int g = 0; g < m->G; g++) { int rc = epi_belief_init_normal(m->b[g], mu, sigma, seed); if (rc) return rc; }
+    return EPI_OK;
+}
+
+int epi_mctx_upload(epi_mctx* m, const int64_t* S, const int64_t* I, const int64_t* R, const int64_t* T)
+{
+    if (!m || !S || !I || !R) return fail(EPI_EINVAL, "epi_mctx_upload: NULL");
+    const int H = m->P.H, D1 = m->P.D + 1;
+    for (int g = 0; g < m->G; g++) {
+        const int64_t s0 = m->start[g];
+        int rc = epi_belief_upload(m->b[g], S + s0, I + s0 * H, R + s0, T ? T + s0 * D1 * H : nullptr);
+        if (rc) return rc;
+    }
+    return EPI_OK;
+}
+
+int epi_mctx_download(epi_mctx* m, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    if (!m) return fail(EPI_EINVAL, "epi_mctx_download: NULL");
+    const int H = m->P.H, D1 = m->P.D + 1;
+    for (int g = 0; g < m->G; g++) {
+        const int64_t s0 = m->start[g];
+        int rc = epi_belief_download(m->b[g], S ? S + s0 : nullptr, I ? I + s0 * H : nullptr, R ? R + s0 : nullptr, T ? T + s0 * D1 * H : nullptr);
+        if (rc) return rc;
+    }
+    return EPI_OK;
+}
+
+int epi_mctx_sums(epi_mctx* m, int64_t* sums)
+{
+    if (!m || !sums) return fail(EPI_EINVAL, "epi_mctx_sums: NULL");
+    const int ns = 2 + m->P.H + (m->P.D + 1) * m->P.H;
+    int64_t part[2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H];
+    for (int j = 0; j < ns; j++) sums[j] = 0;
+    for (int g = 0; g < m->G; g++) {
+        int rc = epi_belief_sums(m->ctx[g], m->b[g], part);
+        if (rc) return rc;
+        for (int j = 0; j < ns; j++) sums[j] += part[j];
+    }
+    return EPI_OK;
+}
+
+int epi_mctx_mean(epi_mctx* m, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    int64_t sums[2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H];
+    int rc = epi_mctx_sums(m, sums);
+    if (rc) return rc;
+    return epi_mean_from_sums(&m->P, m->n_total, sums, S, I, R, T);
+}
+
+int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t step, double* loglik, double* ess, uint32_t* flags, int64_t* moved)
+{
+    return guarded("epi_mpf_update", [&]() -> int {
+        if (!m) return fail(EPI_EINVAL, "epi_mpf_update: NULL");
+        const int G = m->G;
+        const int rows = state_rows(m->P.H, m->P.D);
+        auto dev = [&](int g) { return hipSetDevice(m->device[g]); };
+        auto st = [&](int g) { return m->ctx[g]->stream; };
+        // 1. fused weight + step of every shard; the local maximum log weight stays on its device
+        for (int g = 0; g < G; g++) {
+            int rc = epi_pf_predict_dev(m->ctx[g], m->b[g], a, o, seed, step, m->d_x[g]);
+            if (rc) return rc;
+        }
+        // 2. the global maximum
+        if (m->rccl) {
+            NCCLCHECK(m, m->api.GroupStart());
+            for (int g = 0; g < G; g++) NCCLCHECK(m, m->api.AllReduce(m->d_x[g], m->d_x[g] + 1, 1, ncclDouble, ncclMax, m->comm[g], st(g)));
+            NCCLCHECK(m, m->api.GroupEnd());
+        } else {
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipMemcpyAsync(m->h_x + 8 * g, m->d_x[g], sizeof(double), hipMemcpyDeviceToHost, st(g))); }
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
+            double mx = -INFINITY;
+            for (int g = 0; g < G; g++) mx = m->h_x[8 * g] > mx ? m->h_x[8 * g] : mx;
+            for (int g = 0; g < G; g++) m->h_x[8 * g + 1] = mx;
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipMemcpyAsync(m->d_x[g] + 1, m->h_x + 8 * g + 1, sizeof(double), hipMemcpyHostToDevice, st(g))); }
+        }
+        // 3. fixed-point weights relative to it, local prefix sums, local totals
+        for (int g = 0; g < G; g++) {
+            int rc = epi_pf_weigh_dev(m->ctx[g], m->b[g], m->d_x[g] + 1, m->d_x[g] + 2);
+            if (rc) return rc;
+        }
+        // 4. everyone's totals: {weight total, sum of squares, flags, global maximum} per shard -- the update's one wait
+        std::vector<double> all((size_t)4 * G);
+        if (m->rccl) {
+            NCCLCHECK(m, m->api.GroupStart());
+            for (int g = 0; g < G; g++) NCCLCHECK(m, m->api.AllGather(m->d_x[g] + 2, m->d_x[g] + 8, 4, ncclDouble, m->comm[g], st(g)));
+            NCCLCHECK(m, m->api.GroupEnd());
+            HIPCHECK(dev(0));
+            std::vector<double> tmp((size_t)4 * G);
+            HIPCHECK(hipMemcpyAsync(tmp.data(), m->d_x[0] + 8, sizeof(double) * 4 * (size_t)G, hipMemcpyDeviceToHost, st(0)));
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
+            all = tmp;
+        } else {
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipMemcpyAsync(m->h_x + 8 * g + 2, m->d_x[g] + 2, sizeof(double) * 4, hipMemcpyDeviceToHost, st(g))); }
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
+            for (int g = 0; g < G; g++) for (int k = 0; k < 4; k++) all[(size_t)4 * g + k] = m->h_x[8 * g + 2 + k];
+        }
+        std::vector<uint64_t> w((size_t)G);
+        double sumsq = 0.0;
+        uint32_t fl = 0;
+        unsigned long long W = 0ULL;
+        for (int g = 0; g < G; g++) {
+            w[g] = (uint64_t)all[(size_t)4 * g]; W += w[g];
+            sumsq += all[(size_t)4 * g + 1];
+            fl |= (uint32_t)all[(size_t)4 * g + 2];
+        }
+        const double lwmax = all[3];
+        // 5. the plan: shard g's particles are the ancestors of global slots [lo[g], lo[g + 1])
+        std::vector<int64_t> lo((size_t)G + 1);
+        int rc = epi_pf_plan(m->n_total, G, w.data(), seed, step, lo.data());
+        if (rc) return rc;
+        // 6. particles whose slot another shard owns: packed on the source, copied device to device, placed on the owner
+        // A shard receives at most its own n_local slots, so its receive buffer holds every arriving block side by
+        // side.  A shard that holds most of the weight sends more than n_local slots: blocks go out in pieces of at
+        // most n_local slots through the one send buffer, which the next piece's export may overwrite because it
+        // follows the previous piece's copy on the same stream.
+        struct Block { int from, to; int64_t s0, s1; size_t recv_off; };
+        std::vector<Block> blocks;
+        std::vector<size_t> recv_used((size_t)G, 0);
+        m->moved = 0;
+        for (int g = 0; g < G; g++)
+            for (int h = 0; h < G; h++) {
+                if (h == g) continue;
+                const int64_t s0 = lo[g] > m->start[h] ? lo[g] : m->start[h], s1 = lo[g + 1] < m->start[h + 1] ? lo[g + 1] : m->start[h + 1];
+                const int64_t cap = m->start[g + 1] - m->start[g];
+                for (int64_t p0 = s0; p0 < s1; p0 += cap) {
+                    const int64_t p1 = p0 + cap < s1 ? p0 + cap : s1;
+                    blocks.push_back(Block{g, h, p0, p1, recv_used[h]});
+                    recv_used[h] += (size_t)rows * (size_t)(p1 - p0);
+                    m->moved += p1 - p0;
+                }
+            }
+        for (const Block& k : blocks) {
+            rc = epi_pf_export(m->ctx[k.from], m->b[k.from], G, k.from, w.data(), seed, step, k.s0, k.s1, m->d_send[k.from]);
+            if (rc) return rc;
+            const size_t bytes = sizeof(int32_t) * (size_t)rows * (size_t)(k.s1 - k.s0);
+            HIPCHECK(dev(k.from));
+            if (m->device[k.from] == m->device[k.to])
+                HIPCHECK(hipMemcpyAsync(m->d_recv[k.to] + k.recv_off, m->d_send[k.from], bytes, hipMemcpyDeviceToDevice, st(k.from)));
+            else
+                HIPCHECK(hipMemcpyPeerAsync(m->d_recv[k.to] + k.recv_off, m->device[k.to], m->d_send[k.from], m->device[k.from], bytes, st(k.from)));
+        }
+        for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev[g], st(g))); }
+        // the ancestors of the slots that stay are selected while the copies are in flight
+        for (int g = 0; g < G; g++) {
+            const int64_t s0 = lo[g] > m->start[g] ? lo[g] : m->start[g], s1 = lo[g + 1] < m->start[g + 1] ? lo[g + 1] : m->start[g + 1];
+            if (s1 > s0) { rc = epi_pf_select_local(m->ctx[g], m->b[g], G, g, w.data(), seed, step, s0, s1); if (rc) return rc; }
+        }
+        for (const Block& k : blocks) {
+            HIPCHECK(dev(k.to));
+            HIPCHECK(hipStreamWaitEvent(st(k.to), m->ev[k.from], 0));
+            rc = epi_pf_import(m->ctx[k.to], m->b[k.to], k.s0, k.s1, m->d_recv[k.to] + k.recv_off);
+            if (rc) return rc;
+        }
+        for (int g = 0; g < G; g++) { rc = epi_pf_finish(m->ctx[g], m->b[g], nullptr); if (rc) return rc; }
+        // the next update's exports overwrite the send buffers: their copies must have been consumed, which the
+        // receivers' imports (ordered after the events above) guarantee once every stream has reached this point
+        for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
+        fl |= weight_flags(W, m->n_total);
+        const int F = epi_pf_frac_bits(m->n_total);
+        if (flags) *flags = fl;
+        if (loglik) *loglik = W ? lwmax + log((double)W / ldexp(1.0, F) / (double)m->n_total) - 0.91893853320467274178 : -INFINITY;
+        if (ess) *ess = sumsq > 0.0 ? ((double)W * (double)W) / sumsq : 0.0;
+        if (moved) *moved = m->moved;
         return EPI_OK;
     });
 }

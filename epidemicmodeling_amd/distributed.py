@@ -313,3 +313,67 @@ def _frac_bits(n_total: int) -> int:
     while (1 << lg) < n_total:
         lg += 1
     return min(40, 53 - lg)
+
+
+class NodeFilter:
+    """BootstrapFilter over ONE population sharded across several devices of this host, driven by this process alone
+    (epi_mctx of include/epi.h: the form a single-process host such as Julia uses; ShardedFilter above is the
+    one-process-per-GPU form).  devices: one HIP device per shard; naming a device several times puts several shards on
+    it.  rccl: the small exchanges go through RCCL instead of host memory (needs distinct devices)."""
+
+    def __init__(self, pomdp: CovidPOMDP, n_total: int, devices, seed: int = 0x5EED, rccl: bool = False):
+        self.lib = _lib.load()
+        self.pomdp, self.n_total, self.seed, self.step = pomdp, int(n_total), seed, 0
+        self._cparams = pomdp.to_c()
+        dev = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        check(self.lib.epi_mctx_create(dev, len(devices), C.byref(self._cparams), self.n_total, int(rccl), C.byref(self._h)))
+        self.last_moved = 0
+
+    def init_normal(self, mu: float = 10_000.0, sigma: float = 5_000.0):
+        check(self.lib.epi_mctx_init_normal(self._h, mu, sigma, self.seed))
+
+    def upload(self, S, I, R, T=None):
+        S, I, R = (np.ascontiguousarray(x, dtype=np.int64) for x in (S, I, R))
+        T = None if T is None else np.ascontiguousarray(T, dtype=np.int64)
+        check(self.lib.epi_mctx_upload(self._h, as_i64p(S), as_i64p(I), as_i64p(R), as_i64p(T)))
+
+    def download(self):
+        H, D1, n = self.pomdp.horizon, self.pomdp.test_delay + 1, self.n_total
+        S, R = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        I, T = np.empty((n, H), dtype=np.int64), np.empty((n, H, D1), dtype=np.int64)
+        check(self.lib.epi_mctx_download(self._h, as_i64p(S), as_i64p(I), as_i64p(R), as_i64p(T)))
+        return S, I, R, T
+
+    def update(self, a: float, o: int) -> dict:
+        """update(upd, b, a, o) (src/POMDPsInterface.jl:56) over all shards."""
+        ll, ess, fl, mv = C.c_double(), C.c_double(), C.c_uint32(), C.c_int64()
+        check(self.lib.epi_mpf_update(self._h, float(a), int(o), self.seed, self.step, C.byref(ll), C.byref(ess), C.byref(fl), C.byref(mv)))
+        self.step += 1
+        self.last_moved = mv.value
+        return {"loglik": ll.value, "ess": ess.value, "flags": fl.value, "moved": mv.value}
+
+    def sums(self) -> np.ndarray:
+        p = self.pomdp
+        out = np.zeros(2 + p.horizon + (p.test_delay + 1) * p.horizon, dtype=np.int64)
+        check(self.lib.epi_mctx_sums(self._h, as_i64p(out)))
+        return out
+
+    def mean(self):
+        """mean(pc, pomdp) (src/updater.jl:5-25) of the whole population: (S, I[H], R, Tests[D+1, H])."""
+        H, D1 = self.pomdp.horizon, self.pomdp.test_delay + 1
+        S, R = C.c_int64(), C.c_int64()
+        I, T = np.empty(H, dtype=np.int64), np.empty((H, D1), dtype=np.int64)
+        check(self.lib.epi_mctx_mean(self._h, C.byref(S), as_i64p(I), C.byref(R), as_i64p(T)))
+        return S.value, I, R.value, T.T.copy()
+
+    def close(self):
+        if self._h:
+            self.lib.epi_mctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -235,6 +235,37 @@ int epi_pf_export(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const ui
 int epi_pf_import(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t slot_end, const void *dev_buf);
 int epi_pf_finish(epi_ctx *ctx, epi_belief *b, uint32_t *flags /* NULL: do not fetch */);
 
+/* ---- the same update over the GPUs of a node, behind one call ---------------------- */
+
+/* An epi_mctx is ONE population of n_total particles sharded by index over n_shards devices (shard g holds global
+ * slots [n_total g / G, n_total (g + 1) / G)), driven by the calling host thread: what a Julia host needs to run
+ * update(BootstrapFilter(pomdp, n), b, a, o) (call sites src/POMDPsInterface.jl:56, src/MPC.jl:393) on the eight
+ * GPUs of a node through plain ccall, with no process per GPU and no message passing of its own.  Results are
+ * bit-identical for every number of shards, and equal to epi_pf_update on one device.
+ *   device_ids  one HIP device per shard; a device may be named more than once (several shards share it: how this is
+ *               tested on a machine with one GPU), unless use_rccl is set
+ *   use_rccl    0: the two small exchanges of an update (maximum log weight; four doubles per shard) go through
+ *               page-locked host memory; 1: through RCCL (ncclAllReduce MAX, ncclAllGather, one group call each, over
+ *               xGMI), for which librccl.so is loaded at run time.  Particles that change shard always go device to
+ *               device (hipMemcpyPeerAsync), in packed blocks, pairwise -- no ring.
+ * Memory per shard: the belief with a halo of n_local columns plus one send and one receive buffer of n_local
+ * particles. */
+typedef struct epi_mctx epi_mctx;
+int epi_mctx_create(const int *device_ids, int n_shards, const epi_params *p, int64_t n_total, int use_rccl, epi_mctx **out);
+int epi_mctx_destroy(epi_mctx *m);
+int epi_mctx_shards(const epi_mctx *m);
+int64_t epi_mctx_size(const epi_mctx *m);
+/* initialbelief / ParticleCollection(particles) / particles(b) of the whole population (host layout of this header) */
+int epi_mctx_init_normal(epi_mctx *m, double mu, double sigma, uint64_t seed);
+int epi_mctx_upload(epi_mctx *m, const int64_t *S, const int64_t *I, const int64_t *R, const int64_t *T);
+int epi_mctx_download(epi_mctx *m, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+/* update(upd, b, a, o) over all shards; moved (optional): particles that changed shard in this update */
+int epi_mpf_update(epi_mctx *m, double a, int64_t o, uint64_t seed, uint32_t step,
+                   double *loglik, double *ess, uint32_t *flags, int64_t *moved);
+/* epi_belief_sums / epi_belief_mean of the whole population (integer sums added over shards, rounded once) */
+int epi_mctx_sums(epi_mctx *m, int64_t *sums);
+int epi_mctx_mean(epi_mctx *m, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+
 /* ---- ensembles kept on the device (ODE fitting, src/ODEFit.jl) ------------------ */
 
 typedef struct epi_ensemble epi_ensemble;   /* the histories of n trajectories over T days, resident in HBM */

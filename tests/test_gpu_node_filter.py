@@ -1,0 +1,97 @@
+"""The sharded update behind the C ABI (epi_mctx: one host thread, several shards) against the oracle and against the
+one-device update.  The box has one GPU, so the shards share device 0 and the small exchanges go through host memory;
+the RCCL leg runs with a single shard."""
+import numpy as np
+import pytest
+
+import epidemicmodeling_amd as em
+from epidemicmodeling_amd.distributed import NodeFilter
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+def _ll(info, n):
+    F = pyoracle.lib().orc_frac_bits(n)
+    return info["lwmax"] + np.log(info["W"] / 2.0 ** F / n) - 0.5 * np.log(2 * np.pi)
+
+
+@pytest.mark.parametrize("delay,G", [(0, 1), (0, 2), (0, 5), (1, 3)])
+def test_node_filter_bit_exact(delay, G):
+    """Ragged shards, ordinary and far-out observations (the far one leaves nearly all weight in one shard, which
+    then sends more particles than it holds: the piecewise send path), three updates: every posterior particle, the
+    diagnostics and the belief mean equal the oracle's."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 20_011
+    st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
+    f = NodeFilter(pomdp, n, [0] * G, seed=SEED)
+    f.init_normal()
+    for x, y in zip(f.download(), st):
+        assert (x == y).all()
+    _, mu, _ = orc.log_weights(st, 0.2, 0)
+    moved = []
+    for step, o in enumerate((int(np.median(mu)), int(2.5 * np.median(mu)), int(np.median(mu)) // 2)):
+        got = f.update(0.2, o)
+        st, info = orc.pf_update(st, 0.2, o, SEED, step)
+        assert got["flags"] == info["flags"]
+        assert abs(got["ess"] - info["ess"]) <= 1e-9 * info["ess"]
+        assert abs(got["loglik"] - _ll(info, n)) <= 1e-9 * max(1.0, abs(_ll(info, n)))
+        for name, x, y in zip("SIRT", f.download(), st):
+            assert (x == y).all(), (name, step)
+        moved.append(got["moved"])
+        _, mu, _ = orc.log_weights(st, 0.2, 0)
+    if G > 1:
+        assert max(moved) > n // G                     # some shard sent more than it holds
+    else:
+        assert moved == [0, 0, 0]
+    eS, eI, eR, eT, bad = orc.mean(st)
+    S, I, R, T = f.mean()
+    assert (S, R) == (eS, eR) and (I == eI).all() and (T == eT.T).all() and not bad
+    f.close()
+
+
+def test_node_filter_all_weights_zero_keeps_the_particles():
+    pomdp = em.make_pomdp(LOD=5)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 4_000
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 3)
+    f = NodeFilter(pomdp, n, [0, 0, 0], seed=3)
+    f.init_normal()
+    got = f.update(0.0, 7)                               # a = 0: nobody tested, o = 7 impossible
+    st, info = orc.pf_update(st, 0.0, 7, 3, 0)
+    assert got["flags"] == info["flags"] and got["flags"] & 8 and got["moved"] == 0
+    for x, y in zip(f.download(), st):
+        assert (x == y).all()
+    f.close()
+
+
+def test_node_filter_over_rccl_with_one_shard():
+    """use_rccl = 1: librccl.so is loaded at run time, a communicator of one device is created and the all-reduce and
+    all-gather of an update run on it; the posterior equals the one-device update's."""
+    pomdp = em.make_pomdp(LOD=5)
+    n = 30_000
+    f = NodeFilter(pomdp, n, [0], seed=SEED, rccl=True)
+    f.init_normal()
+    b = em.initialbelief(pomdp, n, seed=SEED)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    for o in (9000, 8000):
+        got = f.update(0.2, o)
+        em.update(upd, b, em.Action(0.2), o)
+        assert (got["loglik"], got["ess"], got["flags"]) == (upd.last_loglik, upd.last_ess, upd.last_flags)
+    for x, y in zip(f.download(), b.download()):
+        assert (x == y).all()
+    f.close(); b.close()
+
+
+def test_node_filter_rejects_what_it_cannot_run():
+    from epidemicmodeling_amd._lib import EpiError
+    pomdp = em.make_pomdp(LOD=5)
+    with pytest.raises(EpiError, match="one device per shard"):
+        NodeFilter(pomdp, 1000, [0, 0], rccl=True)
+    with pytest.raises(EpiError, match="fewer particles than shards"):
+        NodeFilter(pomdp, 2, [0, 0, 0])
+    with pytest.raises(EpiError, match="device"):
+        NodeFilter(pomdp, 1000, [0, 99])

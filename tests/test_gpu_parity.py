@@ -1097,78 +1097,36 @@ def test_population_beyond_two_to_the_31_state_elements(monkeypatch, capsys):
 # the sharded configuration at its full size, all shards in this process
 # ---------------------------------------------------------------------------
 def test_config3_eight_shards_full_size_equal_the_single_update():
-    """10^8 particles as 8 shards of 1.25·10^7 (the multi-GPU configuration, here with every shard on the one GPU and
-    the exchange through device buffers): after each of three updates the shards' column sums add up to those of the
-    one-call update of an unsharded copy, the weight totals and the order statistics of sum(I) agree, and so does
-    every particle of the first and the last shard."""
-    import torch
+    """10^8 particles as 8 shards of 1.25 10^7 (the multi-GPU configuration, here with every shard on the one GPU),
+    updated through the library's own sharded update (epi_mctx: no Python between the phases): after each of three
+    updates the column sums equal those of the one-call update of an unsharded copy, so do log-likelihood, ESS and
+    flags, and at the end every particle of the first and the last shard."""
+    from epidemicmodeling_amd.distributed import NodeFilter
     pomdp = em.make_pomdp()
     ctx = em.interface.context_for(pomdp)
     lib = ctx.lib
     H, D = pomdp.horizon, pomdp.test_delay
     n, G, seed, a = 100_000_000, 8, SEED, 0.2
     nsums = 2 + H + (D + 1) * H
-    rows = lib.epi_state_rows(H, D)
     starts = [(n * g) // G for g in range(G + 1)]
-
-    def sums(b):
-        arr = (C.c_int64 * nsums)()
-        check(lib.epi_belief_sums(ctx.handle, b.handle, arr))
-        return np.array(arr, dtype=np.int64)
-
     single = em.ParticleCollection(ctx, n)
     check(lib.epi_belief_init_normal(single.handle, 10_000.0, 5_000.0, seed))
-    shards = []
-    for g in range(G):
-        m = starts[g + 1] - starts[g]
-        b = em.ParticleCollection(ctx, m, halo_cap=m)
-        check(lib.epi_belief_set_shard(b.handle, n, starts[g]))
-        check(lib.epi_belief_init_normal(b.handle, 10_000.0, 5_000.0, seed))
-        shards.append(b)
+    node = NodeFilter(pomdp, n, [0] * G, seed=seed)
+    node.init_normal()
     for step in range(3):
         o = 9000 - 200 * step
         ll, ess, fl = C.c_double(), C.c_double(), C.c_uint32()
         check(lib.epi_pf_update(ctx.handle, single.handle, a, o, seed, step, C.byref(ll), C.byref(ess), C.byref(fl)))
-        assert fl.value == 0
-        lm = []
-        for b in shards:
-            v = C.c_double()
-            check(lib.epi_pf_predict(ctx.handle, b.handle, a, o, seed, step, C.byref(v)))
-            lm.append(v.value)
-        gmax = max(lm)
-        w = (C.c_uint64 * G)()
-        sumsq = 0.0
-        for g, b in enumerate(shards):
-            wl, sq = C.c_uint64(), C.c_double()
-            check(lib.epi_pf_weigh(ctx.handle, b.handle, gmax, C.byref(wl), C.byref(sq), None))
-            w[g] = wl.value
-            sumsq += sq.value
-        W = float(sum(w))
-        assert abs(W * W / sumsq - ess.value) <= 1e-9 * ess.value
-        lo = (C.c_int64 * (G + 1))()
-        check(lib.epi_pf_plan(n, G, w, seed, step, lo))
-        for g, b in enumerate(shards):           # parents in shard g
-            for h, dst in enumerate(shards):     # slots owned by shard h
-                s0, s1 = max(lo[g], starts[h]), min(lo[g + 1], starts[h + 1])
-                if s1 <= s0:
-                    continue
-                if g == h:
-                    check(lib.epi_pf_select_local(ctx.handle, b.handle, G, g, w, seed, step, s0, s1))
-                else:
-                    buf = torch.empty(rows * (s1 - s0), dtype=torch.int32, device="cuda")
-                    check(lib.epi_pf_export(ctx.handle, b.handle, G, g, w, seed, step, s0, s1, C.c_void_p(buf.data_ptr())))
-                    torch.cuda.synchronize()
-                    check(lib.epi_pf_import(ctx.handle, dst.handle, s0, s1, C.c_void_p(buf.data_ptr())))
-                    torch.cuda.synchronize()
-                    del buf
-        for b in shards:
-            check(lib.epi_pf_finish(ctx.handle, b.handle, None))
-        assert (sum(sums(b) for b in shards) == sums(single)).all()
+        got = node.update(a, o)
+        assert fl.value == 0 and got["flags"] == 0
+        assert got["loglik"] == ll.value and abs(got["ess"] - ess.value) <= 1e-9 * ess.value
+        arr = (C.c_int64 * nsums)()
+        check(lib.epi_belief_sums(ctx.handle, single.handle, arr))
+        assert (node.sums() == np.array(arr, dtype=np.int64)).all()
     S, I, R, T = single.download()
-    for g in (0, G - 1):
-        s, i, r, t = shards[g].download()
-        sl = slice(starts[g], starts[g + 1])
-        assert (s == S[sl]).all() and (i == I[sl]).all() and (r == R[sl]).all() and (t == T[sl]).all()
-    for b in shards:
-        b.close()
     single.close()
+    s, i, r, t = node.download()
+    for g in (0, G - 1):
+        sl = slice(starts[g], starts[g + 1])
+        assert (s[sl] == S[sl]).all() and (i[sl] == I[sl]).all() and (r[sl] == R[sl]).all() and (t[sl] == T[sl]).all()
+    node.close()
