@@ -18,7 +18,7 @@ import POMDPs, ParticleFilters
 import Statistics: mean
 using EpidemicModeling: CovidPOMDP, State, Action
 
-export EpiCtx, GPUBelief, GPUBootstrapFilter, initialbelief, upload!, gen!, score_sequences, closed_loop_days!,
+export EpiCtx, GPUBelief, GPUBootstrapFilter, GPUNodeFilter, initialbelief, upload!, gen!, score_sequences, closed_loop_days!,
        SimulateClosedLoop, unity_test_period, step_variates
 
 const LIBEPI = get(ENV, "EPI_GFX950_LIB", joinpath(@__DIR__, "..", "epidemicmodeling_amd", "csrc", "libepi_gfx950.so"))
@@ -268,6 +268,62 @@ function SimulateClosedLoop(T::Int, state::State, b::GPUBelief, pomdp::CovidPOMD
         day += k
     end
     (sus = sus, inf = inf, rec = rec, N = pomdp.N, T = T, pos_test = tests, actions = acts, rewards = rewards)
+end
+
+# ---- one population over the GPUs of a node (epi_mctx) ------------------------------------------------------------
+# update(BootstrapFilter(pomdp, n), b, a, o) with the particles sharded by index over several devices, from this one
+# Julia process: GPUNodeFilter is updater and belief in one (the particles never leave the devices).
+mutable struct GPUNodeFilter <: POMDPs.Updater
+    h::Ptr{Cvoid}
+    m::CovidPOMDP
+    n::Int
+    seed::UInt64
+    step::UInt32
+    prev_action::Action
+    loglik::Float64
+    ess::Float64
+    flags::UInt32
+    moved::Int64
+end
+function GPUNodeFilter(m::CovidPOMDP, n::Integer; devices::Vector{<:Integer} = collect(0:7), seed::Integer = 0x5EED, rccl::Bool = true)
+    m.test_period == 1 || error("build the filter on unity_test_period(pomdp), as src/POMDPsInterface.jl:38-39 does")
+    h = Ref{Ptr{Cvoid}}(C_NULL); p = Ref(EpiParams(m)); dev = Cint.(devices)
+    check(ccall((:epi_mctx_create, LIBEPI), Cint, (Ptr{Cint}, Cint, Ref{EpiParams}, Int64, Cint, Ref{Ptr{Cvoid}}),
+                dev, length(dev), p, n, rccl, h))
+    f = GPUNodeFilter(h[], m, n, UInt64(seed), UInt32(0), Action(0.0), NaN, NaN, UInt32(0), 0)
+    finalizer(f -> ccall((:epi_mctx_destroy, LIBEPI), Cint, (Ptr{Cvoid},), f.h), f)
+    f
+end
+ParticleFilters.n_particles(f::GPUNodeFilter) = f.n
+
+function initialbelief(f::GPUNodeFilter; μ = 10_000.0, σ = 5_000.0)
+    check(ccall((:epi_mctx_init_normal, LIBEPI), Cint, (Ptr{Cvoid}, Float64, Float64, UInt64), f.h, μ, σ, f.seed))
+    f
+end
+
+function POMDPs.update(f::GPUNodeFilter, b::GPUNodeFilter, a::Action, o::Integer)
+    b === f || error("a GPUNodeFilter updates its own particles")
+    ll = Ref{Float64}(0.0); ess = Ref{Float64}(0.0); fl = Ref{UInt32}(0); mv = Ref{Int64}(0)
+    check(ccall((:epi_mpf_update, LIBEPI), Cint,
+        (Ptr{Cvoid}, Float64, Int64, UInt64, UInt32, Ref{Float64}, Ref{Float64}, Ref{UInt32}, Ref{Int64}),
+        f.h, a.testing_prop, o, f.seed, f.step, ll, ess, fl, mv))
+    f.step += 1
+    f.loglik, f.ess, f.flags, f.moved, f.prev_action = ll[], ess[], fl[], mv[], a
+    f
+end
+
+function mean(f::GPUNodeFilter)
+    H = length(f.m.Infdistributions); D1 = f.m.test_delay + 1
+    S = Ref{Int64}(0); R = Ref{Int64}(0); I = Vector{Int64}(undef, H); T = Matrix{Int64}(undef, D1, H)
+    check(ccall((:epi_mctx_mean, LIBEPI), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ref{Int64}, Ptr{Int64}), f.h, S, I, R, T))
+    State(S[], I, R[], T, f.prev_action)
+end
+
+function ParticleFilters.particles(f::GPUNodeFilter)
+    H = length(f.m.Infdistributions); D1 = f.m.test_delay + 1
+    S = Vector{Int64}(undef, f.n); R = similar(S); I = Matrix{Int64}(undef, H, f.n); T = Array{Int64}(undef, D1, H, f.n)
+    check(ccall((:epi_mctx_download, LIBEPI), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), f.h, S, I, R, T))
+    [State(S[j], I[:, j], R[j], T[:, :, j], f.prev_action) for j in 1:f.n]
 end
 
 # ---- for the parity harness (parity.jl) ---------------------------------------------------------------------------

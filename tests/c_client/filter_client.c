@@ -5,6 +5,7 @@
  * same run made through the Python binding.
  *
  *   filter_client <n> <seed> <action> <o_1> ... <o_k>
+ *   filter_client shards=<G> <n> <seed> <action> <o_1> ... <o_k>     the same population as G shards (epi_mctx), all on device 0
  *
  * Parameters arrive on stdin as text: H D N inf_loss test_loss testrate_loss,
  * then H values each of q, p, k, theta (hex floats are accepted by strtod). */
@@ -25,8 +26,36 @@ static int read_double(double *x)
     return 1;
 }
 
+/* the sharded form: one population over G shards behind epi_mctx (here all on device 0) */
+static int run_sharded(int G, int64_t n, uint64_t seed, double action, const epi_params *P, int n_obs, char **obs)
+{
+    int dev[64];
+    epi_mctx *m = NULL;
+    if (G < 1 || G > 64) { fprintf(stderr, "bad shard count\n"); return 1; }
+    for (int g = 0; g < G; g++) dev[g] = 0;
+    CHECK(epi_mctx_create(dev, G, P, n, 0, &m));
+    CHECK(epi_mctx_init_normal(m, 10000.0, 5000.0, seed));
+    printf("rows %d size %" PRId64 "\n", epi_state_rows(P->H, P->D), epi_mctx_size(m));
+    for (int t = 0; t < n_obs; t++) {
+        double loglik = 0.0, ess = 0.0;
+        uint32_t flags = 0;
+        int64_t moved = 0;
+        CHECK(epi_mpf_update(m, action, strtoll(obs[t], NULL, 10), seed, (uint32_t)t, &loglik, &ess, &flags, &moved));
+        printf("update %d %a %a %u\n", t, loglik, ess, flags);
+    }
+    int64_t mS = 0, mR = 0, mI[EPI_MAX_H], mT[(EPI_MAX_D + 1) * EPI_MAX_H];
+    CHECK(epi_mctx_mean(m, &mS, mI, &mR, mT));
+    printf("mean %" PRId64 " %" PRId64, mS, mR);
+    for (int i = 0; i < P->H; i++) printf(" %" PRId64, mI[i]);
+    printf("\n");
+    CHECK(epi_mctx_destroy(m));
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    int shards = 0;
+    if (argc > 1 && strncmp(argv[1], "shards=", 7) == 0) { shards = atoi(argv[1] + 7); argv++; argc--; }
     if (argc < 5) { fprintf(stderr, "usage: filter_client n seed action o_1 [o_2 ...]\n"); return 1; }
     const int64_t n = strtoll(argv[1], NULL, 10);
     const uint64_t seed = strtoull(argv[2], NULL, 10);
@@ -43,6 +72,8 @@ int main(int argc, char **argv)
     for (int t = 0; t < 4; t++)
         for (int i = 0; i < P.H; i++)
             if (!read_double(&tab[t][i])) { fprintf(stderr, "short parameter input\n"); return 1; }
+
+    if (shards) return run_sharded(shards, n, seed, action, &P, argc - 4, argv + 4);
 
     epi_ctx *ctx = NULL;
     epi_belief *b = NULL;

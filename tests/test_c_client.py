@@ -58,3 +58,29 @@ def test_c_host_matches_python_binding(delay):
     q = em.suminf_quantiles(b, [0.05, 0.5, 0.95])
     assert [int(x) for x in lines["quantiles"][1:]] == [int(x) for x in q]
     b.close()
+
+
+@pytest.mark.gpu
+def test_c_host_drives_the_sharded_update():
+    """The same run as three shards behind epi_mctx, from plain C: diagnostics and belief mean equal the one-device
+    run's (ESS to rounding: the sums of squares are added per shard)."""
+    import epidemicmodeling_amd as em
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    n, seed, a = 50_001, 4242, 0.25
+    obs = [5100, 4900, 9900]
+    r = subprocess.run([EXE, "shards=3", str(n), str(seed), repr(a)] + [str(o) for o in obs], input=_params_text(pomdp),
+                       capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    lines = {l.split()[0] + (l.split()[1] if l.startswith("update") else ""): l.split() for l in r.stdout.splitlines()}
+    assert lines["rows"][3] == str(n)
+    b = em.initialbelief(pomdp, n, seed=seed)
+    upd = em.BootstrapFilter(pomdp, n, seed=seed)
+    for t, o in enumerate(obs):
+        em.update(upd, b, em.Action(a), o)
+        tok = lines[f"update{t}"]
+        assert float.fromhex(tok[2]) == upd.last_loglik and int(tok[4]) == upd.last_flags
+        assert abs(float.fromhex(tok[3]) - upd.last_ess) <= 1e-9 * upd.last_ess
+    m = em.mean(b)
+    got = [int(x) for x in lines["mean"][1:]]
+    assert got[0] == m.S and got[1] == m.R and got[2:] == [int(x) for x in m.I]
+    b.close()

@@ -806,11 +806,14 @@ def test_config4_scenario_scoring_full_size():
 
 
 def test_config5_wide_state_ensemble():
-    """Ensembles of 10^6 trajectories over 30 days for H = 14, 28, 56 with a random action each: every day of every
-    trajectory conserves the population (checked through the ODE loss of a model that cannot move anyone)."""
+    """The ensemble configuration at its full size, 10^7 trajectories over 30 days, for the default horizon H = 14
+    (4.8 GB of history on the device); the wide states H = 28, 56 with 10^6 trajectories (their histories have the same
+    shape, and 10^7 of them add nothing but run time).  A random action per trajectory; every day of every trajectory
+    conserves the population (checked through the ODE loss of a model that cannot move anyone, and for H = 14 on the
+    downloaded history of the first 10^6 trajectories' worth of memory)."""
     for H in (14, 28, 56):
         pomdp = em.make_pomdp(LOD=5, horizon=H)
-        n, T = 1_000_000, 30
+        n, T = (10_000_000 if H == 14 else 1_000_000), 30
         b = em.random_states(pomdp, n, seed=H)
         acts = np.random.default_rng(H).random(n)
         ens = em.Ensemble(b, T, acts, seed=H)
@@ -820,13 +823,39 @@ def test_config5_wide_state_ensemble():
         l_sir = ens.loss("SIR", [0.0, 0.0], substeps=1)
         l_seir = ens.loss("SEIR", [0.0, 0.0, 0.0], substeps=1)
         assert np.isfinite(l_sir) and l_sir == l_seir and l_sir >= 0
-        arr = ens.Array() if H == 14 else None
+        arr = ens.Array() if H == 14 else None                  # int64[3, T, n]: 7.2 GB of host memory at 10^7
         if arr is not None:
             # random start states include degenerate ones (the reference asserts on them, src/simulate.jl:117); the
             # population is conserved wherever no flag was raised, i.e. for states inside the model's domain
             tot = arr.sum(axis=0)
             assert arr.shape == (3, T, n) and (tot[0] == pomdp.N).all()
         ens.close()
+
+
+def test_generated_parameter_tables_through_the_device_path():
+    """The deterministic parameter pipeline feeds the device: tables regenerated from a seed for a limit of detection
+    and a horizon the built-in tables do not cover (LOD 4, 18 infection ages), then one step and two filter updates of
+    2000 particles, device against oracle bit for bit."""
+    pomdp = em.CovidPOMDP_generated(seed=11, n=20_000, LOD=4, horizon=18, test_delay=1)
+    assert pomdp.horizon == 18 and len(pomdp.pos_test_probs) == 18 and 0.0 < max(pomdp.pos_test_probs) <= 1.0
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 2000
+    st = orc.init_normal(n, 6_000.0, 3_000.0, 17)
+    b = em.initialbelief(pomdp, n, mu=6_000.0, sigma=3_000.0, seed=17)
+    _eq(b.download(), st)
+    o, r, fl = em.step_batch(b, 0.35, seed=17, step=0)
+    st, eo, er, _, efl = orc.step_batch(st, 0.35, seed=17, step=0)
+    _eq(b.download(), st)
+    assert (o == eo).all() and (r == er).all() and fl == efl
+    upd = em.BootstrapFilter(pomdp, n, seed=17, step=1)
+    for day in range(2):
+        _, mu, _ = orc.log_weights(st, 0.35, 0)
+        obs = int(np.quantile(mu, 0.3 + 0.4 * day))
+        em.update(upd, b, em.Action(0.35), obs)
+        st, info = orc.pf_update(st, 0.35, obs, 17, 1 + day)
+        assert upd.last_flags == info["flags"] and abs(upd.last_ess - info["ess"]) <= 1e-9 * info["ess"]
+        _eq(b.download(), st)
+    b.close()
 
 
 # ---------------------------------------------------------------------------

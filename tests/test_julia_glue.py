@@ -17,7 +17,7 @@ JULIA = {
     "Cstring": C.c_char_p, "Ptr{Cvoid}": C.c_void_p,
     "Ptr{Int64}": _P(C.c_int64), "Ref{Int64}": _P(C.c_int64), "Ptr{Float64}": _P(C.c_double), "Ref{Float64}": _P(C.c_double),
     "Ptr{UInt32}": _P(C.c_uint32), "Ref{UInt32}": _P(C.c_uint32), "Ptr{UInt64}": _P(C.c_uint64),
-    "Ref{Ptr{Cvoid}}": _P(C.c_void_p), "Ref{EpiParams}": _P(_lib.epi_params),
+    "Ref{Ptr{Cvoid}}": _P(C.c_void_p), "Ref{EpiParams}": _P(_lib.epi_params), "Ptr{Cint}": _P(C.c_int),
 }
 
 
@@ -75,7 +75,7 @@ def test_the_entry_points_a_drop_in_needs_are_bound():
     bound = {name for name, _, _ in _ccalls(SRC)}
     for name in ("epi_ctx_create", "epi_params_set", "epi_belief_create", "epi_belief_upload", "epi_belief_download", "epi_belief_copy",
                  "epi_belief_init_normal", "epi_pf_update", "epi_belief_mean", "epi_belief_sample", "epi_step_batch", "epi_rollout_batch",
-                 "epi_rollout_score", "epi_closed_loop_days", "epi_step_variates", "epi_belief_suminf_quantiles", "epi_last_error"):
+                 "epi_rollout_score", "epi_closed_loop_days", "epi_step_variates", "epi_mctx_create", "epi_mpf_update", "epi_mctx_mean", "epi_mctx_download", "epi_belief_suminf_quantiles", "epi_last_error"):
         assert name in bound, name
 
 
