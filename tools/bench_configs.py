@@ -54,4 +54,6 @@ def ensembles():
 
 
 if __name__ == "__main__":
-    closed_loop(); scoring(); ensembles()
+    which = sys.argv[1:] or ["closed_loop", "scoring", "ensembles"]
+    for name in which:
+        {"closed_loop": closed_loop, "scoring": scoring, "ensembles": ensembles}[name]()

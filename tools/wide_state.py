@@ -1,9 +1,12 @@
+"""Rollout rate against the state width H for the two step kernels (cooperative up to H = 15 by default, one thread
+per particle beyond).  GPU box, repository root: python3 tools/wide_state.py"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import epidemicmodeling_amd as em
 from epidemicmodeling_amd import _lib
-lib = _lib.load()
+# the choice of step kernel is a switch of the testing build (include/epi_testing.h): make it the library every context uses
+lib = _lib._lib = _lib.load_testing()
 for H in (14, 16, 21, 28, 56, 64):
     pomdp = em.make_pomdp(LOD=5, horizon=H)
     n, T = 4_000_000, 10
