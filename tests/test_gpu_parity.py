@@ -304,6 +304,35 @@ def test_closed_loop_days_bit_exact(delay):
     assert upd.step == len(acts)
 
 
+def test_closed_loop_days_rejects_bad_arguments():
+    pomdp = em.make_pomdp(LOD=5)
+    ctx = em.interface.context_for(pomdp)
+    lib = ctx.lib
+    b = em.initialbelief(pomdp, 500, seed=1)
+    true2 = em.initialbelief(pomdp, 2, seed=2)
+    true1 = em.initialbelief(pomdp, 1, seed=2)
+    upd = em.BootstrapFilter(pomdp, 500, seed=1)
+    with pytest.raises(ValueError, match="one particle"):
+        em.interface.closed_loop_days(true2, b, upd, [0.2], 1, 0)
+    acts = np.array([0.2])
+    q5 = np.full(5, 0.5)
+    quant = np.zeros(5, dtype=np.int64)
+
+    def call(truth, belief, ndays, nq, q, quant_out):
+        return lib.epi_closed_loop_days(ctx.handle, truth.handle, belief.handle, ndays, as_f64p(acts), 0.0, 1, 0, 1, 0, nq, as_f64p(q),
+                                        None, None, None, None, None, None, None, as_i64p(quant_out))
+    assert call(true2, b, 1, 0, None, None) == -1 and b"population of one" in lib.epi_last_error()
+    assert call(true1, b, 0, 0, None, None) == -1 and b"ndays" in lib.epi_last_error()
+    assert call(true1, b, 1, 5, q5, quant) == -1 and b"quantiles" in lib.epi_last_error()
+    assert call(b, b, 1, 0, None, None) == -1
+    q_bad = np.array([1.5])
+    assert call(true1, b, 1, 1, q_bad, quant) == -1 and b"q[0]" in lib.epi_last_error()
+    # nothing was advanced by the refused calls
+    assert call(true1, b, 1, 0, None, None) == 0
+    for x in (b, true1, true2):
+        x.close()
+
+
 def test_pf_million_particles_bit_exact():
     """Three successive updates of 10^6 particles against the oracle: every posterior particle, ancestor
     concentration included (the second and third updates resample a belief that already holds duplicates)."""
