@@ -642,7 +642,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 BtrsConsts C;
                 int32_t k = btrs_try(C, n, pp, lpq, Dp->lf, screen, wa, wb);
                 const bool fail = k < 0;
-                const bool pushed = q_push(fail, entry, qnext, &qn[nxt]);
+                // after the last round nothing reads the queue: a draw rejected there ends as in btrs_finish
+                const bool pushed = round + 1u < BINOM_MAX_ATTEMPTS && q_push(fail, entry, qnext, &qn[nxt]);
                 if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);
                 if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
             }
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 gamma_retry(gt, (uint32_t)it, round, zf, wu);
                 double v;
                 const bool ok = gamma_attempt(G, zf, wu, v);
-                const bool pushed = q_push(!ok, entry, qnext, &qn[nxt]);
+                const bool pushed = round + 1u < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt]);   // as above: gamma_finish_from's ending
                 if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
                 else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
             }

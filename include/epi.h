@@ -67,7 +67,8 @@ extern "C" {
  * up to 10^6 particles and for any size while the weights are spread; it grows when 10^7 or more particles collapse
  * onto a few (n = 10^8, F = 26: about 1.5 / (sum of w_i / w_max)).  EPI_F_COARSE_W reports n / W > 10^-3.
  * The samplers cap a rejection draw at 512 attempts (probability of reaching it below 10^-400 for any admissible
- * parameters); a draw that exhausted them would differ between the two step kernels. */
+ * parameters); a draw that exhausted them ends as the binomial's mode, or as the Gamma's unit proposal, in every
+ * step kernel. */
 
 /* Model parameters the step needs: the numeric content of the reference's
  * CovidPOMDP struct (src/typedef.jl:43-56) after its constructor has run
