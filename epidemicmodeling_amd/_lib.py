@@ -105,6 +105,8 @@ SIGNATURES = {
     "epi_pf_select_local": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _u64p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64]),
     "epi_pf_export": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _u64p, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, _vp]),
     "epi_pf_import": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
+    "epi_pf_import_late": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, _vp]),
+    "epi_pf_predict_part_dev": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, _vp]),
     "epi_pf_finish": (C.c_int, [_vp, _vp, _u32p]),
     "epi_belief_sums": (C.c_int, [_vp, _vp, _i64p]),
     "epi_belief_mean": (C.c_int, [_vp, _vp, _i64p, _i64p, _i64p, _i64p]),

@@ -37,6 +37,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "epi_step.hpp"
 
 using namespace epi;
@@ -131,7 +133,10 @@ struct epi_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;
 };
 
-enum Phase { PH_IDLE = 0, PH_PREDICTED = 1, PH_WEIGHED = 2 };
+// PH_PENDING: an update has finished, but some owned slots still wait for particles of other shards (late imports);
+// PH_PARTIAL: the step of the next update has run over some of the shard's columns
+enum Phase { PH_IDLE = 0, PH_PREDICTED = 1, PH_WEIGHED = 2, PH_PENDING = 3, PH_PARTIAL = 4 };
+typedef std::pair<int64_t, int64_t> Span;                   // columns [first, second) of a shard
 
 struct epi_belief {
     epi_ctx* ctx = nullptr;
@@ -152,7 +157,59 @@ struct epi_belief {
     int64_t halo_used = 0;
     int frac_bits = 0;
     uint64_t seed = 0; uint32_t step = 0;
+    // bookkeeping of the phased update: columns that received an ancestor in the update in progress, columns that
+    // still wait for one after epi_pf_finish, columns the step of the next update has covered so far
+    std::vector<Span> filled, unfilled, done;
+    double part_a = 0.0; int64_t part_o = 0;                // arguments of the first epi_pf_predict_part of an update
 };
+
+// back to "no update in progress" (after the population has been replaced)
+static inline void protocol_reset(epi_belief* b)
+{
+    b->phase = PH_IDLE;
+    b->filled.clear(); b->unfilled.clear(); b->done.clear();
+}
+
+static bool spans_overlap(const std::vector<Span>& v, int64_t a, int64_t b)
+{
+    for (const Span& s : v) if (a < s.second && s.first < b) return true;
+    return false;
+}
+
+// the parts of [0, n) that no span covers
+static std::vector<Span> spans_complement(std::vector<Span> v, int64_t n)
+{
+    std::sort(v.begin(), v.end());
+    std::vector<Span> out;
+    int64_t at = 0;
+    for (const Span& s : v) {
+        if (s.first > at) out.emplace_back(at, s.first);
+        if (s.second > at) at = s.second;
+    }
+    if (at < n) out.emplace_back(at, n);
+    return out;
+}
+
+static bool spans_contain(const std::vector<Span>& v, int64_t a, int64_t b)
+{
+    for (const Span& s : v) if (s.first <= a && b <= s.second) return true;
+    return false;
+}
+
+// takes [a, b) out of the spans; false unless one of them contains it
+static bool spans_remove(std::vector<Span>& v, int64_t a, int64_t b)
+{
+    for (size_t k = 0; k < v.size(); k++) {
+        if (v[k].first <= a && b <= v[k].second) {
+            const Span s = v[k];
+            v.erase(v.begin() + (long)k);
+            if (s.first < a) v.emplace_back(s.first, a);
+            if (b < s.second) v.emplace_back(b, s.second);
+            return true;
+        }
+    }
+    return false;
+}
 
 struct epi_ensemble {
     epi_ctx* ctx = nullptr;
@@ -2001,7 +2058,7 @@ int epi_belief_upload(epi_belief* b, const int64_t* S, const int64_t* I, const i
         HIPCHECK(hipMemcpy2D(b->buf[b->cur], sizeof(int32_t) * (size_t)b->stride, h.data(), sizeof(int32_t) * (size_t)n, sizeof(int32_t) * (size_t)n, (size_t)b->rows,
                              hipMemcpyHostToDevice));
         b->has_anc = false;
-        b->phase = PH_IDLE;
+        protocol_reset(b);
         return EPI_OK;
     });
 }
@@ -2053,6 +2110,7 @@ int epi_belief_copy(epi_belief* dst, epi_belief* src)
     if (rc) return rc;
     if (!dst || dst->n != src->n || dst->rows != src->rows || dst->stride != src->stride || dst->ctx != src->ctx)
         return fail(EPI_EINVAL, "epi_belief_copy: beliefs differ in shape or context");
+    if (src->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_copy: a phased update of the source is in progress");
     epi_ctx* c = src->ctx;
     HIPCHECK(hipSetDevice(c->device));
     if (src->has_anc) {
@@ -2065,7 +2123,7 @@ int epi_belief_copy(epi_belief* dst, epi_belief* src)
         HIPCHECK(hipMemcpyAsync(dst->buf[dst->cur], src->buf[src->cur], bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     HIPCHECK(hipStreamSynchronize(c->stream));
-    dst->has_anc = false; dst->n_total = src->n_total; dst->slot0 = src->slot0; dst->phase = PH_IDLE;
+    dst->has_anc = false; dst->n_total = src->n_total; dst->slot0 = src->slot0; protocol_reset(dst);
     return EPI_OK;
 }
 
@@ -2082,7 +2140,7 @@ int epi_belief_init_normal(epi_belief* b, double mu, double sigma, uint64_t seed
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(c->h_pin, over, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(hipStreamSynchronize(c->stream));
-    b->has_anc = false; b->phase = PH_IDLE;
+    b->has_anc = false; protocol_reset(b);
     if (*reinterpret_cast<const unsigned int*>(c->h_pin))
         return fail(EPI_EINVAL, "epi_belief_init_normal: a particle drew more initial infections than the population N = %lld "
                                 "(src/typedef.jl:164 asserts sum(I0) <= N)", (long long)c->P.N);
@@ -2098,7 +2156,7 @@ int epi_belief_init_simplex(epi_belief* b, uint64_t seed)
     k_init_simplex<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, b->buf[b->cur], b->stride, c->P.H, b->rows, (long long)c->P.N, seed, (uint64_t)b->slot0);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(c->stream));
-    b->has_anc = false; b->phase = PH_IDLE;
+    b->has_anc = false; protocol_reset(b);
     return EPI_OK;
 }
 
@@ -2603,17 +2661,24 @@ struct UpdateScratch {
 };
 static inline UpdateScratch own_scratch(epi_belief* b) { return UpdateScratch{b->scal, b->blocksum, b->blocksq, b->big}; }
 
+// The fused step + weight kernel over the columns [col0, col0 + count) of the population (count < 0: all of it).  A
+// range either ends with the population or holds whole workgroups: the surplus threads of a padded launch write the
+// columns after the range's last one.
 static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, double a, int64_t o, uint64_t seed, uint32_t step, bool timed = true,
-                          const int32_t* o_dev = nullptr)
+                          const int32_t* o_dev = nullptr, int64_t col0 = 0, int64_t count = -1)
 {
+    if (count < 0) count = b->n - col0;
     StepArgs A;
     memset(&A, 0, sizeof A);
     A.screen = g_screen; A.padded = 1;
-    A.n = b->n; A.in = b->buf[b->cur]; A.in_stride = b->stride; A.anc = b->has_anc ? b->anc : nullptr;
-    A.out = b->buf[b->cur ^ 1]; A.out_stride = b->stride;
+    A.n = count; A.in_stride = b->stride;
+    // ancestors are columns of the whole input buffer; without them column m is read for slot m
+    A.in = b->has_anc ? b->buf[b->cur] : b->buf[b->cur] + col0;
+    A.anc = b->has_anc ? b->anc + col0 : nullptr;
+    A.out = b->buf[b->cur ^ 1] + col0; A.out_stride = b->stride;
     A.a = a; A.a_row_stride = 1;
-    A.seed = seed; A.step = step; A.slot0 = (uint64_t)b->slot0;
-    A.o = (double)o; A.o_dev = o_dev; A.lw = b->lw; A.scal = sc.scal;
+    A.seed = seed; A.step = step; A.slot0 = (uint64_t)(b->slot0 + col0);
+    A.o = (double)o; A.o_dev = o_dev; A.lw = b->lw + col0; A.scal = sc.scal;
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->timing && timed) {
         HIPCHECK(hipEventCreate(&e0));
@@ -2625,13 +2690,14 @@ static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, do
     HIPCHECK(hipEventRecord(e1, c->stream));
     if (!(c->timing && timed)) c->ev_valid = true;
     b->seed = seed; b->step = step;
-    b->halo_used = 0;
     b->frac_bits = epi_pf_frac_bits(b->n_total);
     return EPI_OK;
 }
 
 static int launch_weigh(epi_ctx* c, epi_belief* b)
 {
+    b->halo_used = 0;                   // the halo of the buffer this update writes starts empty
+    b->filled.clear();
     k_wsum<false><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, b->blocksq);
     k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, b->scal, b->big, 0);
     k_wcum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum);
@@ -2911,6 +2977,43 @@ int epi_pf_predict_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t 
     });
 }
 
+// One part of the step of a sharded update: the columns [col0, col0 + count) of the shard.  The parts of an update
+// may come in any order and must cover the shard exactly once; columns that still wait for a late import cannot be
+// stepped.  The part that completes the cover hands the local maximum log weight over (as epi_pf_predict_dev).
+int epi_pf_predict_part_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, int64_t col0, int64_t count,
+                            double* d_lwmax_local)
+{
+    return guarded("epi_pf_predict_part_dev", [&]() -> int {
+        int rc = belief_check(b, "epi_pf_predict_part_dev");
+        if (rc) return rc;
+        if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_part_dev: bad argument");
+        if (b->phase != PH_IDLE && b->phase != PH_PENDING && b->phase != PH_PARTIAL)
+            return fail(EPI_ESTATE, "epi_pf_predict_part_dev: previous update not finished");
+        if (col0 < 0 || count < 1 || col0 + count > b->n)
+            return fail(EPI_EINVAL, "epi_pf_predict_part_dev: columns [%lld, %lld) outside the shard's %lld", (long long)col0, (long long)(col0 + count), (long long)b->n);
+        if (col0 % CTPB != 0 || (count % CTPB != 0 && col0 + count != b->n))
+            return fail(EPI_EINVAL, "epi_pf_predict_part_dev: a part starts at a multiple of %d columns and holds a multiple of %d, or ends with the shard", CTPB, CTPB);
+        if (b->phase == PH_PARTIAL && (a != b->part_a || o != b->part_o || seed != b->seed || step != b->step))
+            return fail(EPI_EINVAL, "epi_pf_predict_part_dev: the parts of one update must agree in action, observation, seed and step");
+        if (spans_overlap(b->done, col0, col0 + count)) return fail(EPI_ESTATE, "epi_pf_predict_part_dev: columns [%lld, %lld) were stepped already", (long long)col0, (long long)(col0 + count));
+        if (spans_overlap(b->unfilled, col0, col0 + count))
+            return fail(EPI_ESTATE, "epi_pf_predict_part_dev: columns in [%lld, %lld) still wait for particles of another shard (epi_pf_import_late)", (long long)col0, (long long)(col0 + count));
+        HIPCHECK(hipSetDevice(c->device));
+        rc = launch_predict(c, b, own_scratch(b), a, o, seed, step, true, nullptr, col0, count);
+        if (rc) return rc;
+        b->part_a = a; b->part_o = o;
+        b->done.emplace_back(col0, col0 + count);
+        b->phase = PH_PARTIAL;
+        if (spans_complement(b->done, b->n).empty()) {
+            k_scal_export_lwmax<<<1, 1, 0, c->stream>>>(b->scal, d_lwmax_local);
+            HIPCHECK(hipGetLastError());
+            b->done.clear();
+            b->phase = PH_PREDICTED;
+        }
+        return EPI_OK;
+    });
+}
+
 int epi_pf_weigh_dev(epi_ctx* c, epi_belief* b, const double* d_lwmax_global, double* d_totals)
 {
     int rc = belief_check(b, "epi_pf_weigh_dev");
@@ -2982,6 +3085,7 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
     for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
     rc = launch_scatter(c, b, total, off, u, slot_begin, slot_end);
     if (rc) return rc;
+    b->filled.emplace_back(slot_begin - b->slot0, slot_end - b->slot0);
     return EPI_OK;
 }
 
@@ -3007,23 +3111,45 @@ int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w
     return EPI_OK;
 }
 
+// late: after epi_pf_finish, into the buffer that has become the current one
+static int import_block(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf, bool late, const char* who)
+{
+    if (slot_begin < b->slot0 || slot_end > b->slot0 + b->n || slot_begin > slot_end || !dev_buf)
+        return fail(EPI_EINVAL, "%s: slots [%lld, %lld) not owned by this shard", who, (long long)slot_begin, (long long)slot_end);
+    const int64_t count = slot_end - slot_begin;
+    if (count == 0) return EPI_OK;
+    const int64_t col0 = slot_begin - b->slot0;
+    if (late && !spans_contain(b->unfilled, col0, col0 + count))
+        return fail(EPI_ESTATE, "%s: slots [%lld, %lld) do not wait for an import", who, (long long)slot_begin, (long long)slot_end);
+    if (b->halo_used + count > b->halo_cap) return fail(EPI_ERANGE, "%s: halo capacity %lld exceeded", who, (long long)b->halo_cap);
+    if (late) spans_remove(b->unfilled, col0, col0 + count);
+    HIPCHECK(hipSetDevice(c->device));
+    k_import<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, col0, b->n + b->halo_used, static_cast<const int32_t*>(dev_buf),
+                                                                             b->buf[late ? b->cur : b->cur ^ 1], b->stride, b->rows, b->anc);
+    HIPCHECK(hipGetLastError());
+    if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
+    b->halo_used += count;
+    if (!late) b->filled.emplace_back(col0, col0 + count);
+    else if (b->phase == PH_PENDING && b->unfilled.empty()) b->phase = PH_IDLE;
+    return EPI_OK;
+}
+
 int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
 {
     int rc = belief_check(b, "epi_pf_import");
     if (rc) return rc;
+    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_import: belief belongs to another context");
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_import: call epi_pf_weigh first");
-    if (slot_begin < b->slot0 || slot_end > b->slot0 + b->n || slot_begin > slot_end || !dev_buf)
-        return fail(EPI_EINVAL, "epi_pf_import: slots [%lld, %lld) not owned by this shard", (long long)slot_begin, (long long)slot_end);
-    const int64_t count = slot_end - slot_begin;
-    if (count == 0) return EPI_OK;
-    if (b->halo_used + count > b->halo_cap) return fail(EPI_ERANGE, "epi_pf_import: halo capacity %lld exceeded", (long long)b->halo_cap);
-    HIPCHECK(hipSetDevice(c->device));
-    k_import<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin - b->slot0, b->n + b->halo_used, static_cast<const int32_t*>(dev_buf),
-                                                                             b->buf[b->cur ^ 1], b->stride, b->rows, b->anc);
-    HIPCHECK(hipGetLastError());
-    if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
-    b->halo_used += count;
-    return EPI_OK;
+    return import_block(c, b, slot_begin, slot_end, dev_buf, false, "epi_pf_import");
+}
+
+int epi_pf_import_late(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
+{
+    int rc = belief_check(b, "epi_pf_import_late");
+    if (rc) return rc;
+    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_import_late: belief belongs to another context");
+    if (b->phase != PH_PENDING && b->phase != PH_PARTIAL) return fail(EPI_ESTATE, "epi_pf_import_late: no slot waits for an import");
+    return import_block(c, b, slot_begin, slot_end, dev_buf, true, "epi_pf_import_late");
 }
 
 int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
@@ -3037,7 +3163,11 @@ int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
         if (rc) return rc;
     } else HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
     if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
-    b->cur ^= 1; b->has_anc = true; b->phase = PH_IDLE;
+    b->cur ^= 1; b->has_anc = true;
+    // owned slots that neither epi_pf_select_local nor epi_pf_import has given an ancestor wait for epi_pf_import_late
+    b->unfilled = spans_complement(b->filled, b->n);
+    b->filled.clear();
+    b->phase = b->unfilled.empty() ? PH_IDLE : PH_PENDING;
     return EPI_OK;
 }
 

@@ -22,6 +22,12 @@ src/POMDPsInterface.jl:56, src/MPC.jl:393):
      packed and sent directly to the owner (pairwise send/recv, no ring);
      slots owned locally only get an ancestor index (the gather is folded into
      the next step kernel), selected while the exchange is in flight.
+  7. with the device library the update returns while the exchange is still in
+     flight: the NEXT update first steps the slots that were filled locally,
+     then waits for the received blocks, places them and steps the rest, so a
+     transfer over xGMI (64 bytes per particle that changes shard) is hidden
+     behind the step kernel.  Anything else that reads the population settles
+     the exchange first.
 """
 from __future__ import annotations
 
@@ -97,6 +103,11 @@ class LibShard:
         """lwmax_out: 1-element float64 device tensor that receives the local maximum log weight."""
         check(self.lib.epi_pf_predict_dev(self.ctx.handle, self.b.handle, a, int(o), seed, step, C.c_void_p(lwmax_out.data_ptr())))
 
+    def predict_part_dev(self, a, o, seed, step, col0, count, lwmax_out):
+        """The step over the shard's columns [col0, col0 + count); the part that completes the cover writes lwmax_out."""
+        check(self.lib.epi_pf_predict_part_dev(self.ctx.handle, self.b.handle, a, int(o), seed, step, col0, count,
+                                               C.c_void_p(lwmax_out.data_ptr())))
+
     def weigh_dev(self, lwmax_global, totals_out):
         """lwmax_global: 1-element device tensor; totals_out: 4-element device tensor (w, sum w^2, flags, lwmax)."""
         check(self.lib.epi_pf_weigh_dev(self.ctx.handle, self.b.handle, C.c_void_p(lwmax_global.data_ptr()),
@@ -134,6 +145,12 @@ class LibShard:
             self.torch.cuda.current_stream().synchronize()
         check(self.lib.epi_pf_import(self.ctx.handle, self.b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
 
+    def import_late(self, s0, s1, buf):
+        """import_ after finish(): for the slots an update left waiting for their particles."""
+        if not self.shares_stream:
+            self.torch.cuda.current_stream().synchronize()
+        check(self.lib.epi_pf_import_late(self.ctx.handle, self.b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
+
     def finish(self, want_flags: bool = True) -> int:
         fl = C.c_uint32()
         check(self.lib.epi_pf_finish(self.ctx.handle, self.b.handle, C.byref(fl) if want_flags else None))
@@ -159,7 +176,8 @@ class ShardedFilter:
     process group.  `shard` may be supplied (tests use a CPU stand-in with the
     LibShard interface); by default it is the device library."""
 
-    def __init__(self, pomdp: CovidPOMDP, n_total: int, seed: int = 0x5EED, device: int = 0, shard=None):
+    def __init__(self, pomdp: CovidPOMDP, n_total: int, seed: int = 0x5EED, device: int = 0, shard=None,
+                 overlap: Optional[bool] = None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -176,16 +194,53 @@ class ShardedFilter:
         self.stage = dist.get_backend() == "gloo" and torch.device(self.comm_device).type == "cuda"
         self.step = 0
         self.frac_bits = _frac_bits(self.n_total)
+        # overlap: leave an update while its particle exchange is in flight and step around it in the next one
+        self.overlap = hasattr(self.shard, "predict_part_dev") if overlap is None else bool(overlap)
+        self._pending = None            # (requests, receive blocks, locally filled columns, send blocks kept alive)
+        self.updates_in_parts = 0       # updates whose step ran around an exchange in flight
 
     # -- population ---------------------------------------------------------
     def init_normal(self, mu: float, sigma: float):
+        self._pending = None
         self.shard.init_normal(mu, sigma, self.seed)
 
     def upload_local(self, S, I, R, T=None):
+        self._pending = None
         self.shard.upload(S, I, R, T)
 
     def download_local(self):
+        self.settle()
         return self.shard.download()
+
+    def settle(self):
+        """Completes the particle exchange the last update left in flight (a no-op otherwise)."""
+        if self._pending is None:
+            return
+        reqs, recvs, _, _ = self._pending
+        self._pending = None
+        for req in reqs:
+            req.wait()
+        for r0, r1, buf in recvs:
+            self.shard.import_late(r0, r1, buf.to(self.comm_device) if self.stage else buf)
+
+    def _predict_around_the_exchange(self, a, o, seed, step, t):
+        """The step of an update whose predecessor left its exchange in flight: the columns that were filled locally
+        first (whole workgroups of 256), then the received blocks, then the rest."""
+        sh, n = self.shard, self.n_local
+        c0, c1 = self._pending[2]
+        first = -(-c0 // 256) * 256
+        last = c1 if c1 == n else (c1 // 256) * 256
+        if last - first < max(256, n // 4):          # little to hide the transfer behind
+            self.settle()
+            sh.predict_dev(a, o, seed, step, t)
+            return
+        self.updates_in_parts += 1
+        sh.predict_part_dev(a, o, seed, step, first, last - first, t)
+        self.settle()
+        if first > 0:
+            sh.predict_part_dev(a, o, seed, step, 0, first, t)
+        if last < n:
+            sh.predict_part_dev(a, o, seed, step, last, n - last, t)
 
     def timing(self, on: bool):
         self.shard.timing(on)
@@ -221,7 +276,10 @@ class ShardedFilter:
         if device_handover:
             # 1-4 without a host round trip: the library's kernels and the collectives are ordered on one stream
             t = torch.empty(1, dtype=torch.float64, device=self.comm_device)
-            sh.predict_dev(a, o, seed, step, t)
+            if self._pending is not None:
+                self._predict_around_the_exchange(a, o, seed, step, t)
+            else:
+                sh.predict_dev(a, o, seed, step, t)
             self._all_reduce(t, dist.ReduceOp.MAX)
             mine = torch.empty(4, dtype=torch.float64, device=self.comm_device)
             sh.weigh_dev(t, mine)
@@ -247,14 +305,15 @@ class ShardedFilter:
         lo = sh.plan(self.n_total, w_shard, seed, step)
         st = self.starts
         # 6: exchange the particles whose slot is owned by another rank
-        ops, recvs = [], []
+        ops, recvs, sends = [], [], []
         for h in range(G):
             if h == g:
                 continue
             s0, s1 = max(lo[g], st[h]), min(lo[g + 1], st[h + 1])          # my particles -> slots of rank h
             if s1 > s0:
                 blk = sh.export(g, w_shard, seed, step, s0, s1)
-                ops.append(dist.P2POp(dist.isend, blk.cpu() if self.stage else blk, h))
+                sends.append(blk.cpu() if self.stage else blk)
+                ops.append(dist.P2POp(dist.isend, sends[-1], h))
             r0, r1 = max(lo[h], st[g]), min(lo[h + 1], st[g + 1])          # rank h's particles -> my slots
             if r1 > r0:
                 buf = sh.recv_buffer(r1 - r0)
@@ -266,14 +325,19 @@ class ShardedFilter:
         s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
         if s1 > s0:
             sh.select_local(g, w_shard, seed, step, s0, s1)
-        for req in reqs:
-            req.wait()
-        for r0, r1, buf in recvs:
-            sh.import_(r0, r1, buf.to(self.comm_device) if self.stage else buf)
-        if device_handover:
+        if self.overlap and device_handover and recvs:
+            # leave with the exchange in flight: the library records the slots that still wait for their particles
             sh.finish(want_flags=False)
+            self._pending = (reqs, recvs, (s0 - st[g], s1 - st[g]) if s1 > s0 else (0, 0), sends)
         else:
-            sh.finish()
+            for req in reqs:
+                req.wait()
+            for r0, r1, buf in recvs:
+                sh.import_(r0, r1, buf.to(self.comm_device) if self.stage else buf)
+            if device_handover:
+                sh.finish(want_flags=False)
+            else:
+                sh.finish()
         W = sum(w_shard)
         if W == 0:
             flags |= _lib.EPI_F_ZERO_W
@@ -285,6 +349,7 @@ class ShardedFilter:
                 "moved": sum(r1 - r0 for r0, r1, _ in recvs), "w_shard": w_shard, "lo": lo}
 
     def close(self):
+        self.settle()
         if hasattr(self.shard, "close"):
             self.shard.close()
 
@@ -293,6 +358,7 @@ class ShardedFilter:
         """mean(pc, pomdp) (src/updater.jl:5-25) of the whole sharded population:
         integer sums added over ranks, then rounded once."""
         torch, dist = self.torch, self.dist
+        self.settle()
         sums = torch.from_numpy(self.shard.sums()).to(self.comm_device)
         self._all_reduce(sums, dist.ReduceOp.SUM)
         sums = sums.cpu().numpy()

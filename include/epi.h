@@ -235,6 +235,20 @@ int epi_pf_export(epi_ctx *ctx, epi_belief *b, int n_shards, int shard, const ui
                   uint64_t seed, uint32_t step, int64_t slot_begin, int64_t slot_end, void *dev_buf);
 int epi_pf_import(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t slot_end, const void *dev_buf);
 int epi_pf_finish(epi_ctx *ctx, epi_belief *b, uint32_t *flags /* NULL: do not fetch */);
+/* Transfers hidden behind the next step.  Particles that change shard are 64 bytes each over a point-to-point link,
+ * and a shard needs them only for the slots they fill.  A host may therefore call epi_pf_finish before its receives
+ * have completed: the owned slots that neither epi_pf_select_local nor epi_pf_import has filled are then recorded as
+ * waiting, and every call that reads the population refuses (EPI_ESTATE) until they are filled.  The next update of
+ * the same call sites (update(up, b, a, o), src/POMDPsInterface.jl:56) steps the shard in parts:
+ *   epi_pf_predict_part_dev over the columns that were filled locally, while the transfer is in flight;
+ *   epi_pf_import_late for each received block (same packing as epi_pf_import);
+ *   epi_pf_predict_part_dev over the remaining columns.
+ * A part starts at a multiple of 256 columns and holds a multiple of 256, or ends with the shard; the parts of an
+ * update agree in (a, o, seed, step) and cover the shard exactly once; the part that completes the cover writes the
+ * local maximum log weight to d_lwmax_local as epi_pf_predict_dev does, and epi_pf_weigh_dev follows. */
+int epi_pf_predict_part_dev(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step,
+                            int64_t col0, int64_t count, double *d_lwmax_local /* device, 1 double */);
+int epi_pf_import_late(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t slot_end, const void *dev_buf);
 
 /* ---- the same update over the GPUs of a node, behind one call ---------------------- */
 

@@ -27,13 +27,13 @@ def _free_port():
 def _prior(pomdp, n, lopsided):
     orc = pyoracle.Oracle(pomdp.to_c())
     st = orc.init_normal(n, 10_000.0, 5_000.0, 71)
-    if lopsided:                      # far fewer infected in the first half: its weights collapse, particles cross shards
-        st[1][: n // 2] //= 3
+    if lopsided:                      # fewer infected in the first half: its weights fall (True: collapse), particles cross shards
+        st[1][: n // 2] = st[1][: n // 2] * 7 // 8 if lopsided == "tilt" else st[1][: n // 2] // 3
         st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
     return orc, st
 
 
-def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir):
+def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,26 +42,29 @@ def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir):
         _, st = _prior(pomdp, n, lopsided)
         starts = shard_starts(n, world)
         sl = slice(starts[rank], starts[rank + 1])
-        f = ShardedFilter(pomdp, n, seed=1234, device=0)
+        f = ShardedFilter(pomdp, n, seed=1234, device=0, overlap=overlap)
         assert f.stage
         f.upload_local(*(x[sl] for x in st))
         infos = [f.update(a, o) for o in obs]
         S, I, R, T = f.download_local()
         mS, mI, mR, mT = f.mean()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), S=S, I=I, R=R, T=T, mS=mS, mI=mI, mR=mR,
-                 ess=[i["ess"] for i in infos], moved=[i["moved"] for i in infos], flags=[i["flags"] for i in infos])
+                 ess=[i["ess"] for i in infos], moved=[i["moved"] for i in infos], flags=[i["flags"] for i in infos],
+                 in_parts=f.updates_in_parts)
+        f.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("delay,lopsided,world", [(1, True, 2), (0, True, 3), (0, False, 4)])
-def test_device_shards_in_several_processes(tmp_path, delay, lopsided, world):
+@pytest.mark.parametrize("delay,lopsided,world,overlap", [(1, True, 2, True), (1, "tilt", 2, True), (0, "tilt", 3, True), (0, "tilt", 3, False),
+                                                          (0, True, 3, False), (0, False, 4, True)])
+def test_device_shards_in_several_processes(tmp_path, delay, lopsided, world, overlap):
     n, a = 30_011, 0.25
     pomdp = em.make_pomdp(LOD=5, test_delay=delay)
     orc, st = _prior(pomdp, n, lopsided)
     _, mu, _ = orc.log_weights(st, a, 0)
     obs = [int(np.quantile(mu, q)) for q in (0.9, 0.5, 0.7)]
-    mp.spawn(_worker, args=(world, _free_port(), n, delay, lopsided, a, obs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, delay, lopsided, a, obs, str(tmp_path), overlap), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     exp, infos = st, []
     for step, o in enumerate(obs):
@@ -77,3 +80,7 @@ def test_device_shards_in_several_processes(tmp_path, delay, lopsided, world):
         assert (p["flags"] == [i["flags"] for i in infos]).all()
     if lopsided:
         assert sum(int(p["moved"].sum()) for p in parts) > 0          # particles did cross the shard boundary
+    if lopsided == "tilt":
+        # with the overlap on, later updates stepped around the exchange their predecessor had left in flight (a shard
+        # whose weights have collapsed has no slots of its own to step meanwhile, and waits as without the overlap)
+        assert (sum(int(p["in_parts"]) for p in parts) > 0) == overlap

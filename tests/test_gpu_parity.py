@@ -440,6 +440,107 @@ def test_pf_sharded_phases_equal_single_update():
         _eq(tuple(np.concatenate([g_[k] for g_ in got]) for k in range(4)), st)
 
 
+def test_pf_late_imports_and_step_in_parts_equal_single_update():
+    """The phased update left with its exchange open: finish before the received blocks are placed, then the next
+    step in parts around the late imports.  Same posterior as the one-call update; the library refuses everything
+    that would read slots still waiting for their particles."""
+    import torch
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    ctx = em.interface.context_for(pomdp)
+    lib = ctx.lib
+    n, G = 9001, 2
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 71)
+    st[1][: n // 2] = st[1][: n // 2] * 7 // 8       # a tilt: part of the first shard's slots go to the second's particles
+    st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
+    starts = [(n * g) // G for g in range(G + 1)]
+    shards = []
+    for g in range(G):
+        m = starts[g + 1] - starts[g]
+        b = em.ParticleCollection(ctx, m, halo_cap=m)
+        b.upload(*(x[starts[g]:starts[g + 1]] for x in st))
+        check(lib.epi_belief_set_shard(b.handle, n, starts[g]))
+        shards.append(b)
+    a, seed = 0.25, 1234
+    _, mu, _ = orc.log_weights(st, a, 0)
+    o = int(np.quantile(mu, 0.6))
+    rows = lib.epi_state_rows(pomdp.horizon, pomdp.test_delay)
+    late = [[] for _ in range(G)]              # per shard: (slot range, packed block) not placed yet
+    local = [(0, 0)] * G                       # per shard: the columns its own particles filled
+    dl = torch.empty(G, dtype=torch.float64, device="cuda")
+    parts_run = 0
+    for step in range(4):
+        lm = []
+        for g, b in enumerate(shards):
+            m = starts[g + 1] - starts[g]
+            dptr = C.c_void_p(dl[g:].data_ptr())
+            if not late[g]:
+                check(lib.epi_pf_predict_dev(ctx.handle, b.handle, a, o, seed, step, dptr))
+            else:
+                c0, c1 = local[g]
+                first, last = -(-c0 // 256) * 256, (c1 if c1 == m else (c1 // 256) * 256)
+                # nothing may read the waiting slots
+                assert lib.epi_pf_predict_dev(ctx.handle, b.handle, a, o, seed, step, dptr) == -5
+                assert lib.epi_belief_sums(ctx.handle, b.handle, as_i64p(np.zeros(64, dtype=np.int64))) == -5
+                assert lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, 0, m, dptr) == -5
+                if last <= first:              # (nearly) every slot comes from the other shard: place them, then one step
+                    for (s0, s1), buf in late[g]:
+                        check(lib.epi_pf_import_late(ctx.handle, b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
+                    late[g] = []
+                    check(lib.epi_pf_predict_dev(ctx.handle, b.handle, a, o, seed, step, dptr))
+                    continue
+                # parts hold whole workgroups
+                assert lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, first + 1, 256, dptr) == -1
+                check(lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, first, last - first, dptr))
+                assert lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, first, last - first, dptr) == -5
+                assert lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a + 0.1, o, seed, step, 0, first, dptr) == -1
+                for (s0, s1), buf in late[g]:
+                    assert lib.epi_pf_import_late(ctx.handle, b.handle, s0 - 1, s1, C.c_void_p(buf.data_ptr())) != 0
+                    check(lib.epi_pf_import_late(ctx.handle, b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
+                    assert lib.epi_pf_import_late(ctx.handle, b.handle, s0, s1, C.c_void_p(buf.data_ptr())) == -5
+                late[g] = []
+                if first > 0:
+                    check(lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, 0, first, dptr))
+                if last < m:
+                    check(lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, last, m - last, dptr))
+                parts_run += 1
+        torch.cuda.synchronize()
+        gmax = float(dl.max().item())
+        w = (C.c_uint64 * G)()
+        for g, b in enumerate(shards):
+            wl, sq = C.c_uint64(), C.c_double()
+            check(lib.epi_pf_weigh(ctx.handle, b.handle, gmax, C.byref(wl), C.byref(sq), None))
+            w[g] = wl.value
+        lo = (C.c_int64 * (G + 1))()
+        check(lib.epi_pf_plan(n, G, w, seed, step, lo))
+        local = [(0, 0)] * G
+        for g, b in enumerate(shards):
+            for h, dst in enumerate(shards):
+                s0, s1 = max(lo[g], starts[h]), min(lo[g + 1], starts[h + 1])
+                if s1 <= s0:
+                    continue
+                if g == h:
+                    check(lib.epi_pf_select_local(ctx.handle, b.handle, G, g, w, seed, step, s0, s1))
+                    local[g] = (s0 - starts[g], s1 - starts[g])
+                else:
+                    buf = torch.empty(rows * (s1 - s0), dtype=torch.int32, device="cuda")
+                    check(lib.epi_pf_export(ctx.handle, b.handle, G, g, w, seed, step, s0, s1, C.c_void_p(buf.data_ptr())))
+                    late[h].append(((s0, s1), buf))
+        for b in shards:
+            check(lib.epi_pf_finish(ctx.handle, b.handle, None))
+        st, info = orc.pf_update(st, a, o, seed, step)
+    assert parts_run >= 1, parts_run
+    # the posterior is readable once the last blocks are in place
+    for g, b in enumerate(shards):
+        if late[g]:
+            with pytest.raises(Exception):
+                b.download()
+        for (s0, s1), buf in late[g]:
+            check(lib.epi_pf_import_late(ctx.handle, b.handle, s0, s1, C.c_void_p(buf.data_ptr())))
+    got = [b.download() for b in shards]
+    _eq(tuple(np.concatenate([g_[k] for g_ in got]) for k in range(4)), st)
+
+
 # ---------------------------------------------------------------------------
 # rollouts
 # ---------------------------------------------------------------------------
