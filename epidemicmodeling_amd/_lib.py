@@ -93,6 +93,8 @@ SIGNATURES = {
     "epi_mctx_upload": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "epi_mctx_download": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "epi_mpf_update": (C.c_int, [_vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32, _f64p, _f64p, _u32p, _i64p]),
+    "epi_mctx_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "epi_mctx_overlapped_updates": (C.c_int64, [_vp]),
     "epi_mctx_sums": (C.c_int, [_vp, _i64p]),
     "epi_mctx_mean": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "epi_pf_frac_bits": (C.c_int, [C.c_int64]),

@@ -3502,6 +3502,15 @@ struct epi_mctx {
     std::vector<double*> d_x;               // per shard, on its device: [0] local max, [1] global max, [2..6) totals, [8 .. 8 + 4 G) all totals
     std::vector<int32_t*> d_send, d_recv;   // per shard: packed blocks leaving / arriving (rows x n_local int32 each)
     std::vector<hipEvent_t> ev;             // per shard: its outgoing copies are complete
+    // An update normally returns with its copies in flight on the shards' copy streams; the next one steps the slots
+    // that were filled locally first, then places the blocks, then steps the rest (epi_pf_predict_part_dev).
+    std::vector<hipStream_t> cs;            // per shard: the stream its outgoing copies run on
+    std::vector<hipEvent_t> ev_exp;         // per shard: its blocks are packed (main stream)
+    struct Block { int from, to; int64_t s0, s1; size_t send_off, recv_off; };
+    std::vector<Block> late;                // blocks of the last update that are not placed yet
+    std::vector<Span> kept;                 // per shard: the columns its own particles filled in the last update
+    bool overlap = true;
+    int64_t overlapped = 0;                 // updates whose step ran around blocks in flight (on at least one shard)
     double* h_x = nullptr;                  // page-locked: 8 doubles per shard
     bool rccl = false;
     RcclApi api;
@@ -3519,13 +3528,18 @@ int epi_mctx_destroy(epi_mctx* m)
 {
     if (!m) return EPI_OK;
     for (int g = 0; g < (int)m->ctx.size(); g++) {
-        if (m->ctx[g]) { (void)hipSetDevice(m->device[g]); (void)hipStreamSynchronize(m->ctx[g]->stream); }
+        if (!m->ctx[g]) continue;
+        (void)hipSetDevice(m->device[g]);
+        (void)hipStreamSynchronize(m->ctx[g]->stream);
+        if (g < (int)m->cs.size() && m->cs[g]) (void)hipStreamSynchronize(m->cs[g]);   // copies into other shards' buffers
     }
     for (size_t g = 0; g < m->comm.size(); g++) if (m->comm[g]) (void)m->api.CommDestroy(m->comm[g]);
     for (int g = 0; g < (int)m->ctx.size(); g++) {
         if (!m->ctx[g]) continue;                               // creation stopped before this shard (its device may not even exist)
         (void)hipSetDevice(m->device[g]);
         if (g < (int)m->ev.size() && m->ev[g]) (void)hipEventDestroy(m->ev[g]);
+        if (g < (int)m->ev_exp.size() && m->ev_exp[g]) (void)hipEventDestroy(m->ev_exp[g]);
+        if (g < (int)m->cs.size() && m->cs[g]) (void)hipStreamDestroy(m->cs[g]);
         if (g < (int)m->d_x.size() && m->d_x[g]) (void)hipFree(m->d_x[g]);
         if (g < (int)m->d_send.size() && m->d_send[g]) (void)hipFree(m->d_send[g]);
         if (g < (int)m->d_recv.size() && m->d_recv[g]) (void)hipFree(m->d_recv[g]);
@@ -3553,7 +3567,7 @@ int epi_mctx_create(const int* device_ids, int n_shards, const epi_params* p, in
         m->G = G; m->n_total = n_total; m->P = *p; m->rccl = use_rccl != 0;
         m->device.assign(device_ids, device_ids + G);
         m->ctx.assign(G, nullptr); m->b.assign(G, nullptr); m->d_x.assign(G, nullptr); m->d_send.assign(G, nullptr); m->d_recv.assign(G, nullptr);
-        m->ev.assign(G, nullptr);
+        m->ev.assign(G, nullptr); m->ev_exp.assign(G, nullptr); m->cs.assign(G, nullptr); m->kept.assign(G, Span(0, 0));
         m->start.resize(G + 1);
         for (int g = 0; g <= G; g++) m->start[g] = shard_start(n_total, G, g);
         const int rows = state_rows(p->H, p->D);
@@ -3576,6 +3590,8 @@ int epi_mctx_create(const int* device_ids, int n_shards, const epi_params* p, in
                 HIPCHECK(hipMalloc((void**)&m->d_recv[g], sizeof(int32_t) * (size_t)rows * (size_t)nl));
             }
             HIPCHECK(hipEventCreateWithFlags(&m->ev[g], hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&m->ev_exp[g], hipEventDisableTiming));
+            HIPCHECK(hipStreamCreateWithFlags(&m->cs[g], hipStreamNonBlocking));
             for (int h = 0; h < g; h++) {                       // direct copies between the two devices where the hardware allows
                 if (device_ids[h] == device_ids[g]) continue;
                 int can = 0;
@@ -3602,9 +3618,40 @@ int epi_mctx_create(const int* device_ids, int n_shards, const epi_params* p, in
 int epi_mctx_shards(const epi_mctx* m) { return m ? m->G : 0; }
 int64_t epi_mctx_size(const epi_mctx* m) { return m ? m->n_total : 0; }
 
+int64_t epi_mctx_overlapped_updates(const epi_mctx* m) { return m ? m->overlapped : 0; }
+
+int epi_mctx_set_overlap(epi_mctx* m, int enable)
+{
+    if (!m) return fail(EPI_EINVAL, "epi_mctx_set_overlap: NULL");
+    m->overlap = enable != 0;
+    return EPI_OK;
+}
+
+// the population is being replaced: blocks in flight are let land and forgotten
+static void mctx_drop_late(epi_mctx* m)
+{
+    if (m->late.empty()) return;
+    for (int g = 0; g < m->G; g++) { (void)hipSetDevice(m->device[g]); (void)hipStreamSynchronize(m->cs[g]); }
+    m->late.clear();
+}
+
+// places the blocks the last update left in flight (each owner's stream waits for the sender's copies)
+static int mctx_settle(epi_mctx* m)
+{
+    for (const epi_mctx::Block& k : m->late) {
+        HIPCHECK(hipSetDevice(m->device[k.to]));
+        HIPCHECK(hipStreamWaitEvent(m->ctx[k.to]->stream, m->ev[k.from], 0));
+        int rc = epi_pf_import_late(m->ctx[k.to], m->b[k.to], k.s0, k.s1, m->d_recv[k.to] + k.recv_off);
+        if (rc) return rc;
+    }
+    m->late.clear();
+    return EPI_OK;
+}
+
 int epi_mctx_init_normal(epi_mctx* m, double mu, double sigma, uint64_t seed)
 {
     if (!m) return fail(EPI_EINVAL, "epi_mctx_init_normal: NULL");
+    mctx_drop_late(m);
     for (int g = 0; g < m->G; g++) { int rc = epi_belief_init_normal(m->b[g], mu, sigma, seed); if (rc) return rc; }
     return EPI_OK;
 }
@@ -3612,6 +3659,7 @@ int epi_mctx_init_normal(epi_mctx* m, double mu, double sigma, uint64_t seed)
 int epi_mctx_upload(epi_mctx* m, const int64_t* S, const int64_t* I, const int64_t* R, const int64_t* T)
 {
     if (!m || !S || !I || !R) return fail(EPI_EINVAL, "epi_mctx_upload: NULL");
+    mctx_drop_late(m);
     const int H = m->P.H, D1 = m->P.D + 1;
     for (int g = 0; g < m->G; g++) {
         const int64_t s0 = m->start[g];
@@ -3624,6 +3672,7 @@ int epi_mctx_upload(epi_mctx* m, const int64_t* S, const int64_t* I, const int64
 int epi_mctx_download(epi_mctx* m, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
 {
     if (!m) return fail(EPI_EINVAL, "epi_mctx_download: NULL");
+    if (int rs = mctx_settle(m)) return rs;
     const int H = m->P.H, D1 = m->P.D + 1;
     for (int g = 0; g < m->G; g++) {
         const int64_t s0 = m->start[g];
@@ -3636,6 +3685,7 @@ int epi_mctx_download(epi_mctx* m, int64_t* S, int64_t* I, int64_t* R, int64_t* 
 int epi_mctx_sums(epi_mctx* m, int64_t* sums)
 {
     if (!m || !sums) return fail(EPI_EINVAL, "epi_mctx_sums: NULL");
+    if (int rs = mctx_settle(m)) return rs;
     const int ns = 2 + m->P.H + (m->P.D + 1) * m->P.H;
     int64_t part[2 + EPI_MAX_H + (EPI_MAX_D + 1) * EPI_MAX_H];
     for (int j = 0; j < ns; j++) sums[j] = 0;
@@ -3663,9 +3713,32 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
         const int rows = state_rows(m->P.H, m->P.D);
         auto dev = [&](int g) { return hipSetDevice(m->device[g]); };
         auto st = [&](int g) { return m->ctx[g]->stream; };
-        // 1. fused weight + step of every shard; the local maximum log weight stays on its device
+        // 1. fused weight + step of every shard; the local maximum log weight stays on its device.  With blocks of the
+        // last update still in flight: first the columns every shard filled from its own particles (whole workgroups),
+        // then the blocks, then the rest.
+        typedef epi_mctx::Block Block;
+        std::vector<Span> inner((size_t)G, Span(0, 0));
+        if (!m->late.empty()) {
+            for (int g = 0; g < G; g++) {
+                const int64_t nl = m->start[g + 1] - m->start[g];
+                const int64_t first = ceil_div(m->kept[g].first, CTPB) * CTPB;
+                const int64_t last = m->kept[g].second == nl ? nl : m->kept[g].second / CTPB * CTPB;
+                if (m->b[g]->phase != PH_PENDING || last - first < (nl / 4 > CTPB ? nl / 4 : CTPB)) continue;   // nothing waits, or little to hide it behind
+                int rc = epi_pf_predict_part_dev(m->ctx[g], m->b[g], a, o, seed, step, first, last - first, m->d_x[g]);
+                if (rc) return rc;
+                inner[g] = Span(first, last);
+            }
+            for (int g = 0; g < G; g++) if (inner[g].second > inner[g].first) { m->overlapped++; break; }
+            if (int rs = mctx_settle(m)) return rs;
+        }
         for (int g = 0; g < G; g++) {
-            int rc = epi_pf_predict_dev(m->ctx[g], m->b[g], a, o, seed, step, m->d_x[g]);
+            const int64_t nl = m->start[g + 1] - m->start[g];
+            int rc = EPI_OK;
+            if (inner[g].second == inner[g].first) rc = epi_pf_predict_dev(m->ctx[g], m->b[g], a, o, seed, step, m->d_x[g]);
+            else {
+                if (inner[g].first > 0) rc = epi_pf_predict_part_dev(m->ctx[g], m->b[g], a, o, seed, step, 0, inner[g].first, m->d_x[g]);
+                if (!rc && inner[g].second < nl) rc = epi_pf_predict_part_dev(m->ctx[g], m->b[g], a, o, seed, step, inner[g].second, nl - inner[g].second, m->d_x[g]);
+            }
             if (rc) return rc;
         }
         // 2. the global maximum
@@ -3721,9 +3794,13 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
         // side.  A shard that holds most of the weight sends more than n_local slots: blocks go out in pieces of at
         // most n_local slots through the one send buffer, which the next piece's export may overwrite because it
         // follows the previous piece's copy on the same stream.
-        struct Block { int from, to; int64_t s0, s1; size_t recv_off; };
+        // When no shard sends more than it owns (the usual case) the blocks lie side by side in the send buffers too, the
+        // copies run on the senders' copy streams, and the update returns with them in flight: the next update (or
+        // whatever reads the population next) places the blocks.  Buffers are reused one update later, after the host
+        // has waited for that update's weight totals on every main stream, i.e. after every import of this one.
         std::vector<Block> blocks;
-        std::vector<size_t> recv_used((size_t)G, 0);
+        std::vector<size_t> recv_used((size_t)G, 0), send_used((size_t)G, 0);
+        bool side_by_side = true;
         m->moved = 0;
         for (int g = 0; g < G; g++)
             for (int h = 0; h < G; h++) {
@@ -3732,37 +3809,65 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
                 const int64_t cap = m->start[g + 1] - m->start[g];
                 for (int64_t p0 = s0; p0 < s1; p0 += cap) {
                     const int64_t p1 = p0 + cap < s1 ? p0 + cap : s1;
-                    blocks.push_back(Block{g, h, p0, p1, recv_used[h]});
+                    blocks.push_back(Block{g, h, p0, p1, send_used[g], recv_used[h]});
                     recv_used[h] += (size_t)rows * (size_t)(p1 - p0);
+                    send_used[g] += (size_t)rows * (size_t)(p1 - p0);
+                    if (send_used[g] > (size_t)rows * (size_t)cap) side_by_side = false;
                     m->moved += p1 - p0;
                 }
             }
+        const bool in_flight = m->overlap && side_by_side && !blocks.empty();
         for (const Block& k : blocks) {
-            rc = epi_pf_export(m->ctx[k.from], m->b[k.from], G, k.from, w.data(), seed, step, k.s0, k.s1, m->d_send[k.from]);
+            int32_t* const src = m->d_send[k.from] + (in_flight ? k.send_off : 0);
+            rc = epi_pf_export(m->ctx[k.from], m->b[k.from], G, k.from, w.data(), seed, step, k.s0, k.s1, src);
             if (rc) return rc;
+            if (in_flight) continue;
             const size_t bytes = sizeof(int32_t) * (size_t)rows * (size_t)(k.s1 - k.s0);
             HIPCHECK(dev(k.from));
             if (m->device[k.from] == m->device[k.to])
-                HIPCHECK(hipMemcpyAsync(m->d_recv[k.to] + k.recv_off, m->d_send[k.from], bytes, hipMemcpyDeviceToDevice, st(k.from)));
+                HIPCHECK(hipMemcpyAsync(m->d_recv[k.to] + k.recv_off, src, bytes, hipMemcpyDeviceToDevice, st(k.from)));
             else
-                HIPCHECK(hipMemcpyPeerAsync(m->d_recv[k.to] + k.recv_off, m->device[k.to], m->d_send[k.from], m->device[k.from], bytes, st(k.from)));
+                HIPCHECK(hipMemcpyPeerAsync(m->d_recv[k.to] + k.recv_off, m->device[k.to], src, m->device[k.from], bytes, st(k.from)));
         }
-        for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev[g], st(g))); }
+        if (in_flight) {
+            for (int g = 0; g < G; g++) {
+                if (!send_used[g]) continue;
+                HIPCHECK(dev(g));
+                HIPCHECK(hipEventRecord(m->ev_exp[g], st(g)));
+                HIPCHECK(hipStreamWaitEvent(m->cs[g], m->ev_exp[g], 0));
+            }
+            for (const Block& k : blocks) {
+                const size_t bytes = sizeof(int32_t) * (size_t)rows * (size_t)(k.s1 - k.s0);
+                HIPCHECK(dev(k.from));
+                if (m->device[k.from] == m->device[k.to])
+                    HIPCHECK(hipMemcpyAsync(m->d_recv[k.to] + k.recv_off, m->d_send[k.from] + k.send_off, bytes, hipMemcpyDeviceToDevice, m->cs[k.from]));
+                else
+                    HIPCHECK(hipMemcpyPeerAsync(m->d_recv[k.to] + k.recv_off, m->device[k.to], m->d_send[k.from] + k.send_off, m->device[k.from], bytes, m->cs[k.from]));
+            }
+            for (int g = 0; g < G; g++) { if (!send_used[g]) continue; HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev[g], m->cs[g])); }
+        } else
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev[g], st(g))); }
         // the ancestors of the slots that stay are selected while the copies are in flight
         for (int g = 0; g < G; g++) {
             const int64_t s0 = lo[g] > m->start[g] ? lo[g] : m->start[g], s1 = lo[g + 1] < m->start[g + 1] ? lo[g + 1] : m->start[g + 1];
+            m->kept[g] = s1 > s0 ? Span(s0 - m->start[g], s1 - m->start[g]) : Span(0, 0);
             if (s1 > s0) { rc = epi_pf_select_local(m->ctx[g], m->b[g], G, g, w.data(), seed, step, s0, s1); if (rc) return rc; }
         }
-        for (const Block& k : blocks) {
-            HIPCHECK(dev(k.to));
-            HIPCHECK(hipStreamWaitEvent(st(k.to), m->ev[k.from], 0));
-            rc = epi_pf_import(m->ctx[k.to], m->b[k.to], k.s0, k.s1, m->d_recv[k.to] + k.recv_off);
-            if (rc) return rc;
+        if (in_flight) {
+            for (int g = 0; g < G; g++) { rc = epi_pf_finish(m->ctx[g], m->b[g], nullptr); if (rc) return rc; }
+            m->late = blocks;
+        } else {
+            for (const Block& k : blocks) {
+                HIPCHECK(dev(k.to));
+                HIPCHECK(hipStreamWaitEvent(st(k.to), m->ev[k.from], 0));
+                rc = epi_pf_import(m->ctx[k.to], m->b[k.to], k.s0, k.s1, m->d_recv[k.to] + k.recv_off);
+                if (rc) return rc;
+            }
+            for (int g = 0; g < G; g++) { rc = epi_pf_finish(m->ctx[g], m->b[g], nullptr); if (rc) return rc; }
+            // the next update's exports overwrite the send buffers: their copies must have been consumed, which the
+            // receivers' imports (ordered after the events above) guarantee once every stream has reached this point
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
         }
-        for (int g = 0; g < G; g++) { rc = epi_pf_finish(m->ctx[g], m->b[g], nullptr); if (rc) return rc; }
-        // the next update's exports overwrite the send buffers: their copies must have been consumed, which the
-        // receivers' imports (ordered after the events above) guarantee once every stream has reached this point
-        for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
         fl |= weight_flags(W, m->n_total);
         const int F = epi_pf_frac_bits(m->n_total);
         if (flags) *flags = fl;

@@ -387,7 +387,7 @@ class NodeFilter:
     one-process-per-GPU form).  devices: one HIP device per shard; naming a device several times puts several shards on
     it.  rccl: the small exchanges go through RCCL instead of host memory (needs distinct devices)."""
 
-    def __init__(self, pomdp: CovidPOMDP, n_total: int, devices, seed: int = 0x5EED, rccl: bool = False):
+    def __init__(self, pomdp: CovidPOMDP, n_total: int, devices, seed: int = 0x5EED, rccl: bool = False, overlap: bool = True):
         self.lib = _lib.load()
         self.pomdp, self.n_total, self.seed, self.step = pomdp, int(n_total), seed, 0
         self._cparams = pomdp.to_c()
@@ -395,6 +395,8 @@ class NodeFilter:
         self._h = C.c_void_p()
         check(self.lib.epi_mctx_create(dev, len(devices), C.byref(self._cparams), self.n_total, int(rccl), C.byref(self._h)))
         self.last_moved = 0
+        if not overlap:         # every update places the particles it received before it returns
+            check(self.lib.epi_mctx_set_overlap(self._h, 0))
 
     def init_normal(self, mu: float = 10_000.0, sigma: float = 5_000.0):
         check(self.lib.epi_mctx_init_normal(self._h, mu, sigma, self.seed))
@@ -418,6 +420,11 @@ class NodeFilter:
         self.step += 1
         self.last_moved = mv.value
         return {"loglik": ll.value, "ess": ess.value, "flags": fl.value, "moved": mv.value}
+
+    @property
+    def overlapped_updates(self) -> int:
+        """Updates so far whose step ran around particle blocks still in flight from the update before."""
+        return int(self.lib.epi_mctx_overlapped_updates(self._h))
 
     def sums(self) -> np.ndarray:
         p = self.pomdp

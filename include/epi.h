@@ -274,9 +274,16 @@ int64_t epi_mctx_size(const epi_mctx *m);
 int epi_mctx_init_normal(epi_mctx *m, double mu, double sigma, uint64_t seed);
 int epi_mctx_upload(epi_mctx *m, const int64_t *S, const int64_t *I, const int64_t *R, const int64_t *T);
 int epi_mctx_download(epi_mctx *m, int64_t *S, int64_t *I, int64_t *R, int64_t *T);
-/* update(upd, b, a, o) over all shards; moved (optional): particles that changed shard in this update */
+/* update(upd, b, a, o) over all shards; moved (optional): particles that changed shard in this update.
+ * Unless a shard sends more particles than it owns (collapsed weights), the call returns with the device-to-device
+ * copies in flight on streams of their own; the next update steps the slots that each shard filled from its own
+ * particles while they travel, then places the blocks and steps the rest (epi_pf_predict_part_dev /
+ * epi_pf_import_late), and any other call that reads the population places them first.  The posterior is the same
+ * either way; epi_mctx_set_overlap(m, 0) makes every update place its blocks before it returns. */
 int epi_mpf_update(epi_mctx *m, double a, int64_t o, uint64_t seed, uint32_t step,
                    double *loglik, double *ess, uint32_t *flags, int64_t *moved);
+int epi_mctx_set_overlap(epi_mctx *m, int enable);
+int64_t epi_mctx_overlapped_updates(const epi_mctx *m);   /* updates so far whose step ran around blocks in flight */
 /* epi_belief_sums / epi_belief_mean of the whole population (integer sums added over shards, rounded once) */
 int epi_mctx_sums(epi_mctx *m, int64_t *sums);
 int epi_mctx_mean(epi_mctx *m, int64_t *S, int64_t *I, int64_t *R, int64_t *T);

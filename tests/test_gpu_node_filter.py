@@ -53,6 +53,39 @@ def test_node_filter_bit_exact(delay, G):
     f.close()
 
 
+@pytest.mark.parametrize("delay,G,overlap", [(0, 3, True), (0, 3, False), (1, 5, True), (0, 8, True)])
+def test_node_filter_updates_back_to_back(delay, G, overlap):
+    """Five updates with nothing read in between: from the second on, an update finds the blocks of its predecessor
+    still in flight and steps around them (unless told not to); the posterior after the last equals the oracle's."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 50_021
+    st = orc.init_normal(n, 10_000.0, 5_000.0, SEED)
+    st[1][: n // 2] = st[1][: n // 2] * 15 // 16         # a tilt between the halves: particles change shard every update
+    st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
+    f = NodeFilter(pomdp, n, [0] * G, seed=SEED, overlap=overlap)
+    f.upload(*st)
+    _, mu, _ = orc.log_weights(st, 0.2, 0)
+    o = int(np.median(mu))
+    moved = 0
+    for step in range(5):
+        got = f.update(0.2, o)
+        st, info = orc.pf_update(st, 0.2, o, SEED, step)
+        assert got["flags"] == info["flags"] and abs(got["ess"] - info["ess"]) <= 1e-9 * info["ess"]
+        moved += got["moved"]
+    assert moved > 0
+    assert (f.overlapped_updates > 0) == overlap
+    for name, x, y in zip("SIRT", f.download(), st):
+        assert (x == y).all(), name
+    # and on from there, after the population has been read
+    got = f.update(0.2, o)
+    st, info = orc.pf_update(st, 0.2, o, SEED, 5)
+    eS, eI, eR, eT, bad = orc.mean(st)
+    S, I, R, T = f.mean()
+    assert (S, R) == (eS, eR) and (I == eI).all() and (T == eT.T).all() and not bad
+    f.close()
+
+
 def test_node_filter_all_weights_zero_keeps_the_particles():
     pomdp = em.make_pomdp(LOD=5)
     orc = pyoracle.Oracle(pomdp.to_c())
