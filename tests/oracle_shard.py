@@ -114,3 +114,78 @@ class OracleShard:
     def sums(self):
         S, I, R, T = self.state
         return np.concatenate([[S.sum(), R.sum()], I.sum(axis=0), T.sum(axis=0).reshape(-1)]).astype(np.int64)
+
+
+class OracleShardDev(OracleShard):
+    """The same stand-in with the device library's hand-over interface (scalars through tensors, the step in parts,
+    imports after finish), so that ShardedFilter's overlapped exchange runs under gloo on CPU too.  Like the library it
+    keeps track of the owned slots that still wait for their particles and refuses to step them."""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self.waiting = np.zeros(self.n, bool)          # slots without a particle after the last finish
+        self.filled = np.zeros(self.n, bool)
+        self.done = np.zeros(self.n, bool)             # columns stepped so far in the update in progress
+
+    def upload(self, S, I, R, T=None):
+        super().upload(S, I, R, T)
+        self.waiting[:] = False
+
+    def download(self):
+        assert not self.waiting.any(), "slots still wait for particles"
+        return self.state
+
+    def sums(self):
+        assert not self.waiting.any(), "slots still wait for particles"
+        return super().sums()
+
+    def predict_dev(self, a, o, seed, step, t):
+        assert not self.waiting.any() and not self.done.any()
+        t[0] = self.predict(a, o, seed, step)
+        self.filled[:] = False
+
+    def predict_part_dev(self, a, o, seed, step, col0, count, t):
+        sl = slice(col0, col0 + count)
+        assert col0 % 256 == 0 and (count % 256 == 0 or col0 + count == self.n)
+        assert not self.waiting[sl].any(), "columns still wait for particles of another shard"
+        assert not self.done[sl].any()
+        if not self.done.any():
+            self.lw = np.empty(self.n)
+            self.prop = tuple(np.empty_like(x) for x in self.state)
+            self.flags = 0
+        sub = tuple(x[sl] for x in self.state)
+        self.lw[sl], _, _ = self.orc.log_weights(sub, a, o)
+        prop, _, _, _, fl = self.orc.step_batch(sub, a, seed=seed, step=step, particle0=self.slot0 + col0)
+        for dst, src in zip(self.prop, prop):
+            dst[sl] = src
+        self.flags |= int(fl)
+        self.done[sl] = True
+        if self.done.all():
+            self.done[:] = False
+            self.filled[:] = False
+            self.new = tuple(np.empty_like(x) for x in self.prop)
+            t[0] = float(self.lw.max())
+
+    def weigh_dev(self, t, mine):
+        w, sq, fl = self.weigh(float(t[0]))
+        mine[0], mine[1], mine[2], mine[3] = float(w), sq, float(fl), float(t[0])
+
+    def select_local(self, g, w_shard, seed, step, s0, s1):
+        super().select_local(g, w_shard, seed, step, s0, s1)
+        self.filled[s0 - self.slot0:s1 - self.slot0] = True
+
+    def import_(self, s0, s1, buf):
+        super().import_(s0, s1, buf)
+        self.filled[s0 - self.slot0:s1 - self.slot0] = True
+
+    def import_late(self, s0, s1, buf):
+        sl = slice(s0 - self.slot0, s1 - self.slot0)
+        assert self.waiting[sl].all(), "slots do not wait for an import"
+        self.new = self.state                            # after finish the received particles go into the current population
+        super().import_(s0, s1, buf)
+        self.waiting[sl] = False
+
+    def finish(self, want_flags=True):
+        self.state = self.new
+        self.waiting = ~self.filled
+        return int(self.flags)

@@ -16,7 +16,7 @@ import epidemicmodeling_amd as em
 from epidemicmodeling_amd import _lib
 from epidemicmodeling_amd.distributed import ShardedFilter, shard_starts
 from oracle import pyoracle
-from oracle_shard import OracleShard
+from oracle_shard import OracleShard, OracleShardDev
 
 
 def _free_port():
@@ -28,13 +28,13 @@ def _free_port():
 def _prior(pomdp, n, lopsided):
     orc = pyoracle.Oracle(pomdp.to_c())
     st = orc.init_normal(n, 10_000.0, 5_000.0, 71)
-    if lopsided:                      # far fewer infected in the first half: its weights collapse, particles cross shards
-        st[1][: n // 2] //= 3
+    if lopsided:                      # fewer infected in the first half: its weights fall (True: collapse), particles cross shards
+        st[1][: n // 2] = st[1][: n // 2] * 7 // 8 if lopsided == "tilt" else st[1][: n // 2] // 3
         st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
     return orc, st
 
 
-def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir):
+def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir, handover=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -42,7 +42,9 @@ def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir):
         _, st = _prior(pomdp, n, lopsided)
         starts = shard_starts(n, world)
         sl = slice(starts[rank], starts[rank + 1])
-        f = ShardedFilter(pomdp, n, seed=1234, shard=OracleShard(pomdp, starts[rank + 1] - starts[rank], n, starts[rank]))
+        shard = (OracleShardDev if handover else OracleShard)(pomdp, starts[rank + 1] - starts[rank], n, starts[rank])
+        f = ShardedFilter(pomdp, n, seed=1234, shard=shard)
+        assert f.overlap == handover
         f.upload_local(*(x[sl] for x in st))
         infos = []
         for o in obs:
@@ -51,7 +53,7 @@ def _worker(rank, world, port, n, delay, lopsided, a, obs, out_dir):
         mS, mI, mR, mT = f.mean()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), S=S, I=I, R=R, T=T, mS=mS, mI=mI, mR=mR, mT=mT,
                  ess=[i["ess"] for i in infos], ll=[i["loglik"] for i in infos], moved=[i["moved"] for i in infos],
-                 flags=[i["flags"] for i in infos])
+                 flags=[i["flags"] for i in infos], in_parts=f.updates_in_parts)
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +81,35 @@ def test_sharded_update_equals_single_process(tmp_path, delay, lopsided, world):
         assert (p["flags"] == [i["flags"] for i in infos]).all()
     if lopsided:
         assert sum(int(p["moved"].sum()) for p in parts) > 0          # particles did cross the shard boundary
+
+
+@pytest.mark.parametrize("delay,lopsided,world", [(0, "tilt", 2), (1, "tilt", 3), (0, True, 2)])
+def test_sharded_update_with_the_exchange_left_in_flight(tmp_path, delay, lopsided, world):
+    """The hand-over interface of the device library on the stand-in: updates return with their exchange in flight, the
+    next one steps the locally filled columns first (whole workgroups of 256), places the received blocks and steps the
+    rest.  Same posterior as the single-process update."""
+    n, a = 6007, 0.25
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc, st = _prior(pomdp, n, lopsided)
+    _, mu, _ = orc.log_weights(st, a, 0)
+    obs = [int(np.quantile(mu, q)) for q in (0.6, 0.5, 0.7, 0.5)]
+    mp.spawn(_worker, args=(world, _free_port(), n, delay, lopsided, a, obs, str(tmp_path), True), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    exp, infos = st, []
+    for step, o in enumerate(obs):
+        exp, info = orc.pf_update(exp, a, o, 1234, step)
+        infos.append(info)
+    for k, name in enumerate("SIRT"):
+        got = np.concatenate([p[name] for p in parts])
+        assert (got == exp[k]).all(), name
+    eS, eI, eR, eT, _ = orc.mean(exp)
+    for p in parts:
+        assert int(p["mS"]) == eS and int(p["mR"]) == eR and (p["mI"] == eI).all() and (p["mT"] == eT.T).all()
+        assert np.allclose(p["ess"], [i["ess"] for i in infos], rtol=1e-9)
+        assert (p["flags"] == [i["flags"] for i in infos]).all()
+    assert sum(int(p["moved"].sum()) for p in parts) > 0
+    if lopsided == "tilt":
+        assert sum(int(p["in_parts"]) for p in parts) > 0             # some update did step around blocks in flight
 
 
 def test_plan_matches_standin_and_covers_all_slots():
