@@ -697,7 +697,8 @@ EPI_HD bool gamma_attempt(const GammaConsts& G, float xf, uint32_t wu, double& v
 }
 
 // U^(1/shape) of the boost for shape < 1 (out of line on the device, for the same reason as binom_inversion)
-EPI_HD_OUTLINE double gamma_boost(double shape, const Rng& g, uint32_t bin)
+// (the generator by value: a reference would put the caller's copy on the stack, 20 bytes per lane stored by every step)
+EPI_HD_OUTLINE double gamma_boost(double shape, const Rng g, uint32_t bin)
 {
     uint32_t wb[4];
     rng_block(g, K_BOOST, bin, 0, wb);
