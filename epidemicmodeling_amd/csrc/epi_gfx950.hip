@@ -534,7 +534,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
 
     const int tid = threadIdx.x;
-    const int64_t base = ((int64_t)blockIdx.x + A.block0) * CTPB;
+    // Workgroups are dealt to the 8 XCDs in turn (b and b + 8 share one, with its L2).  In the full-population build the
+    // workgroups of one XCD take a contiguous share of the particles, so that the lines of the ancestor gather which two
+    // neighbouring tiles both touch are fetched into one L2 instead of two.  (Which tile a workgroup steps has no
+    // bearing on the result: variates are addressed by slot.)
+    unsigned int tile = blockIdx.x;
+    if (FULL) {
+        const unsigned int nb = gridDim.x, x = blockIdx.x & 7u, q = nb >> 3, r = nb & 7u;
+        tile = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+    }
+    const int64_t base = ((int64_t)tile + A.block0) * CTPB;
     const int64_t m = base + tid;
     const bool active = FULL ? true : m < A.n;
     const int64_t mc = FULL ? (m < A.n ? m : A.n - 1) : m;                         // the particle this thread reads
