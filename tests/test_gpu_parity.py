@@ -541,6 +541,34 @@ def test_pf_late_imports_and_step_in_parts_equal_single_update():
     _eq(tuple(np.concatenate([g_[k] for g_ in got]) for k in range(4)), st)
 
 
+@pytest.mark.parametrize("delay", [0, 2])
+def test_step_in_parts_of_a_fresh_population_equals_the_whole_step(delay):
+    """epi_pf_predict_part_dev on a population without an ancestor index (just uploaded): three parts in scrambled order,
+    the last one ragged, then the rest of the update; same posterior as the one-call update."""
+    import torch
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 256 * 5 + 77
+    st = orc.init_normal(n, 10_000.0, 5_000.0, 5)
+    b = _belief(pomdp, st)
+    ctx, lib = b.ctx, b.ctx.lib
+    a, seed = 0.3, 99
+    _, mu, _ = orc.log_weights(st, a, 0)
+    o = int(np.median(mu))
+    d = torch.full((5,), -1.0, dtype=torch.float64, device="cuda")
+    for step in range(2):                       # the second update reads through the ancestor index
+        for col0, count in ((512, n - 512), (0, 256), (256, 256)):
+            check(lib.epi_pf_predict_part_dev(ctx.handle, b.handle, a, o, seed, step, col0, count, C.c_void_p(d.data_ptr())))
+        check(lib.epi_pf_weigh_dev(ctx.handle, b.handle, C.c_void_p(d.data_ptr()), C.c_void_p(d[1:].data_ptr())))
+        torch.cuda.synchronize()
+        w = (C.c_uint64 * 1)(int(d[1].item()))
+        check(lib.epi_pf_select_local(ctx.handle, b.handle, 1, 0, w, seed, step, 0, n))
+        check(lib.epi_pf_finish(ctx.handle, b.handle, None))
+        st, info = orc.pf_update(st, a, o, seed, step)
+        _eq(b.download(), st)
+        assert float(d[0].item()) == info["lwmax"]
+
+
 # ---------------------------------------------------------------------------
 # rollouts
 # ---------------------------------------------------------------------------
