@@ -295,6 +295,16 @@ struct StepArgs {
 
 enum { MODE_PHILOX = 0, MODE_INJECT = 1, MODE_RECORD = 2 };
 
+// Workgroups are dealt to the 8 XCDs in turn (b and b + 8 share one, with its L2).  The step kernels give the
+// workgroups of one XCD a contiguous share of the tiles, so that the lines of the ancestor gather which two neighbouring
+// tiles both touch are fetched into one L2 instead of two: a bijection of [0, gridDim.x) for every grid size.  (Which
+// tile a workgroup steps has no bearing on the result: variates are addressed by slot.)
+__device__ __forceinline__ unsigned int xcd_tile()
+{
+    const unsigned int nb = gridDim.x, x = blockIdx.x & 7u, q = nb >> 3, r = nb & 7u;
+    return x * q + (x < r ? x : r) + (blockIdx.x >> 3);
+}
+
 constexpr int THREAD_WAVES = 4;        // waves per SIMD the per-thread step kernel is allocated for (128 VGPRs; 13 % faster than 3 waves)
 // SCREEN = true: the samplers' binary32 screens are on at compile time (production); false: the run-time flag decides
 template <bool WEIGH, int MODE, bool DELAY = true, bool SCREEN = false>
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(TPB, THREAD_WAVES) void k_step(const StepArgs A, co
 {
     const epi_params& P = Dp->P;
     __shared__ unsigned long long s_max[TPB / 64];
-    const int64_t m = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const int64_t m = (int64_t)xcd_tile() * TPB + threadIdx.x;
     unsigned long long code = 0ULL;       // below every real code
     unsigned int flags = 0;
     if (m < A.n) {
@@ -534,16 +544,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
 
     const int tid = threadIdx.x;
-    // Workgroups are dealt to the 8 XCDs in turn (b and b + 8 share one, with its L2).  In the full-population build the
-    // workgroups of one XCD take a contiguous share of the particles, so that the lines of the ancestor gather which two
-    // neighbouring tiles both touch are fetched into one L2 instead of two.  (Which tile a workgroup steps has no
-    // bearing on the result: variates are addressed by slot.)
-    unsigned int tile = blockIdx.x;
-    if (FULL) {
-        const unsigned int nb = gridDim.x, x = blockIdx.x & 7u, q = nb >> 3, r = nb & 7u;
-        tile = x * q + (x < r ? x : r) + (blockIdx.x >> 3);
-    }
-    const int64_t base = ((int64_t)tile + A.block0) * CTPB;
+    const int64_t base = ((int64_t)xcd_tile() + A.block0) * CTPB;
     const int64_t m = base + tid;
     const bool active = FULL ? true : m < A.n;
     const int64_t mc = FULL ? (m < A.n ? m : A.n - 1) : m;                         // the particle this thread reads
