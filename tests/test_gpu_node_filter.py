@@ -86,6 +86,38 @@ def test_node_filter_updates_back_to_back(delay, G, overlap):
     f.close()
 
 
+def test_node_filter_random_shapes_and_observations():
+    """Small random populations over 1 to 8 shards (some shards smaller than a workgroup), five updates each with
+    observations from typical to impossible and now and then no testing at all (every weight zero), nothing read in
+    between: collapses onto one shard, exchanges left in flight and updates that keep every particle follow each other in
+    every order.  Posterior and diagnostics equal the oracle's."""
+    rng = np.random.default_rng(20261111)
+    pomdp = em.make_pomdp(LOD=5, test_delay=1)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    for case in range(24):
+        G = int(rng.integers(1, 9))
+        n = int(rng.integers(max(G, 50), 6000))
+        seed = int(rng.integers(1, 2 ** 31))
+        st = orc.init_normal(n, 10_000.0, 5_000.0, seed)
+        tilt = rng.random()
+        st[1][: n // 2] = (st[1][: n // 2] * (0.8 + 0.2 * tilt)).astype(np.int64)
+        st[0][:] = pomdp.N - st[1].sum(axis=1) - st[2]
+        f = NodeFilter(pomdp, n, [0] * G, seed=seed, overlap=bool(case % 4))
+        f.upload(*st)
+        for step in range(5):
+            a = 0.0 if rng.random() < 0.15 else float(rng.uniform(0.05, 0.6))
+            _, mu, _ = orc.log_weights(st, a, 0)
+            kind = rng.random()
+            o = int(np.quantile(mu, rng.random())) if kind < 0.7 else int(mu.max() * rng.uniform(1.5, 4.0)) + 3
+            got = f.update(a, o)
+            st, info = orc.pf_update(st, a, o, seed, step)
+            assert got["flags"] == info["flags"], (case, step)
+            assert abs(got["ess"] - info["ess"]) <= 1e-9 * max(info["ess"], 1.0), (case, step)
+        for name, x, y in zip("SIRT", f.download(), st):
+            assert (x == y).all(), (case, name)
+        f.close()
+
+
 def test_node_filter_all_weights_zero_keeps_the_particles():
     pomdp = em.make_pomdp(LOD=5)
     orc = pyoracle.Oracle(pomdp.to_c())
