@@ -159,6 +159,7 @@ struct epi_belief {
     uint64_t seed = 0; uint32_t step = 0;
     // bookkeeping of the phased update: columns that received an ancestor in the update in progress, columns that
     // still wait for one after epi_pf_finish, columns the step of the next update has covered so far
+    bool cum_ready = false;             // the update in progress has written its cumulative weights (over the log weights)
     std::vector<Span> filled, unfilled, done;
     double part_a = 0.0; int64_t part_o = 0;                // arguments of the first epi_pf_predict_part of an update
 };
@@ -1157,6 +1158,78 @@ __global__ __launch_bounds__(TPB) void k_scatter(int64_t n_local, const unsigned
     if (len > BIG_RANGE) {
         const unsigned long long pos = atomicAdd(big_count, 1ULL);
         big[pos] = BigRange{(long long)a, (long long)b, (long long)i};
+    }
+}
+
+// k_wcum and k_scatter in one pass for a shard: the cumulative weights are written (k_export searches them) and go
+// straight from the registers into the ancestor scatter of the owned slots [slot_lo, slot_hi).  W, off, stepw,
+// inv_stepw as for k_scatter.
+__global__ __launch_bounds__(TPB) void k_wcum_scatter_shard(int64_t n, double* __restrict__ lw_then_cum, const DevScalars* __restrict__ scal, int F,
+                                                             const unsigned long long* __restrict__ blockoff, unsigned long long W, unsigned long long off,
+                                                             double stepw, double inv_stepw, int64_t n_total, double u, int64_t slot_lo, int64_t slot_hi,
+                                                             int64_t slot0, int32_t* __restrict__ anc, unsigned long long* __restrict__ big_count,
+                                                             BigRange* __restrict__ big)
+{
+    __shared__ unsigned long long s_w[TPB / 64];
+    const double lwmax = scal->lwmax;
+    const double scale = u2d((uint64_t)(F + 1023) << 52);
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long v[SCAN_ITEMS];
+    unsigned long long run = 0ULL;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        int64_t i = base + j;
+        unsigned long long w = (i < n) ? quantize(lw_then_cum[i], lwmax, scale) : 0ULL;
+        run += w;
+        v[j] = run;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long incl = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = shfl_up_u64(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    unsigned long long before = blockoff[blockIdx.x] + (incl - run);       // local cumulative weight before this thread's particles
+    for (int w = 0; w < wv; w++) before += s_w[w];
+    unsigned long long* cum = reinterpret_cast<unsigned long long*>(lw_then_cum);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) cum[base + j] = before + v[j];
+    if (W == 0ULL) {                                                        // every weight zero: keep the particles in place
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const int64_t i = base + j;
+            if (i < n && slot0 + i >= slot_lo && slot0 + i < slot_hi) anc[i] = (int32_t)i;
+        }
+        return;
+    }
+    int64_t a = base == 0 ? slot_lo : first_slot(off + before, stepw, inv_stepw, u, n_total);
+    a = a < slot_lo ? slot_lo : (a > slot_hi ? slot_hi : a);
+#pragma unroll 1
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const int64_t i = base + j;
+        int64_t b = a;
+        if (i < n) {
+            b = i == n - 1 ? slot_hi : first_slot(off + before + v[j], stepw, inv_stepw, u, n_total);
+            b = b < a ? a : (b > slot_hi ? slot_hi : b);
+        }
+        const int64_t len = b - a;
+        if (len > 0 && len <= SMALL_RANGE)
+            for (int64_t k = 0; k < len; k++) anc[a - slot0 + k] = (int32_t)i;
+        unsigned long long mask = __ballot(len > SMALL_RANGE && len <= BIG_RANGE);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ULL;
+            const int64_t a_l = (int64_t)__shfl((unsigned int)(a >> 32), l, 64) << 32 | (int64_t)__shfl((unsigned int)a, l, 64);
+            const int len_l = __shfl((int)len, l, 64);
+            const int idx_l = __shfl((int)i, l, 64);
+            for (int k = lane; k < len_l; k += 64) anc[a_l - slot0 + k] = idx_l;
+        }
+        if (len > BIG_RANGE) {
+            const unsigned long long pos = atomicAdd(big_count, 1ULL);
+            big[pos] = BigRange{(long long)a, (long long)b, (long long)i};
+        }
+        a = b;
     }
 }
 
@@ -2710,8 +2783,18 @@ static int launch_weigh(epi_ctx* c, epi_belief* b)
     b->filled.clear();
     k_wsum<false><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, b->blocksq);
     k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, b->scal, b->big, 0);
+    HIPCHECK(hipGetLastError());
+    b->cum_ready = false;               // written by whichever comes first: the ancestors of the owned slots, or an export
+    return EPI_OK;
+}
+
+// the cumulative fixed-point weights of the shard, for k_export's search, unless the update has them already
+static int ensure_cum(epi_ctx* c, epi_belief* b)
+{
+    if (b->cum_ready) return EPI_OK;
     k_wcum<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum);
     HIPCHECK(hipGetLastError());
+    b->cum_ready = true;
     return EPI_OK;
 }
 
@@ -2721,6 +2804,12 @@ static int launch_scatter(epi_ctx* c, epi_belief* b, unsigned long long W, unsig
 {
     BigRange* list = reinterpret_cast<BigRange*>(b->big + 2);
     const double stepw = W ? (double)W / (double)b->n_total : 0.0, inv_stepw = W ? (double)b->n_total / (double)W : 0.0;
+    if (!b->cum_ready) {
+        // nothing has needed the cumulative weights yet: they are computed, written and used in one pass
+        k_wcum_scatter_shard<<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, W, off, stepw, inv_stepw,
+                                                                                    b->n_total, u, slot_lo, slot_hi, b->slot0, b->anc, b->big, list);
+        b->cum_ready = true;
+    } else
     k_scatter<<<dim3((unsigned)ceil_div(b->n, TPB)), dim3(TPB), 0, c->stream>>>(b->n, reinterpret_cast<const unsigned long long*>(b->lw), W, off, stepw, inv_stepw,
                                                                                b->n_total, u, slot_lo, slot_hi, b->slot0, b->anc, b->big, list);
     int64_t gx = ceil_div(slot_hi - slot_lo, (int64_t)TPB * 8);
@@ -3109,6 +3198,8 @@ int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w
     if (slot_begin == slot_end) return EPI_OK;
     HIPCHECK(hipSetDevice(c->device));
     rc = set_offsets(c, b, G, shard, w_shard);
+    if (rc) return rc;
+    rc = ensure_cum(c, b);
     if (rc) return rc;
     const double u = resample_offset(seed, step);
     const int64_t count = slot_end - slot_begin;
@@ -3827,6 +3918,12 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
                 }
             }
         const bool in_flight = m->overlap && side_by_side && !blocks.empty();
+        // the ancestors of the slots that stay come first: that pass also leaves the cumulative weights the exports search
+        for (int g = 0; g < G; g++) {
+            const int64_t s0 = lo[g] > m->start[g] ? lo[g] : m->start[g], s1 = lo[g + 1] < m->start[g + 1] ? lo[g + 1] : m->start[g + 1];
+            m->kept[g] = s1 > s0 ? Span(s0 - m->start[g], s1 - m->start[g]) : Span(0, 0);
+            if (s1 > s0) { rc = epi_pf_select_local(m->ctx[g], m->b[g], G, g, w.data(), seed, step, s0, s1); if (rc) return rc; }
+        }
         for (const Block& k : blocks) {
             int32_t* const src = m->d_send[k.from] + (in_flight ? k.send_off : 0);
             rc = epi_pf_export(m->ctx[k.from], m->b[k.from], G, k.from, w.data(), seed, step, k.s0, k.s1, src);
@@ -3857,12 +3954,6 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
             for (int g = 0; g < G; g++) { if (!send_used[g]) continue; HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev[g], m->cs[g])); }
         } else
             for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev[g], st(g))); }
-        // the ancestors of the slots that stay are selected while the copies are in flight
-        for (int g = 0; g < G; g++) {
-            const int64_t s0 = lo[g] > m->start[g] ? lo[g] : m->start[g], s1 = lo[g + 1] < m->start[g + 1] ? lo[g + 1] : m->start[g + 1];
-            m->kept[g] = s1 > s0 ? Span(s0 - m->start[g], s1 - m->start[g]) : Span(0, 0);
-            if (s1 > s0) { rc = epi_pf_select_local(m->ctx[g], m->b[g], G, g, w.data(), seed, step, s0, s1); if (rc) return rc; }
-        }
         if (in_flight) {
             for (int g = 0; g < G; g++) { rc = epi_pf_finish(m->ctx[g], m->b[g], nullptr); if (rc) return rc; }
             m->late = blocks;

@@ -304,7 +304,13 @@ class ShardedFilter:
         # 5: the plan (identical on every rank)
         lo = sh.plan(self.n_total, w_shard, seed, step)
         st = self.starts
-        # 6: exchange the particles whose slot is owned by another rank
+        # 6: the ancestors of the slots that stay on this rank come first: with the device library that pass also
+        # leaves the cumulative weights which the exports search
+        s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
+        if s1 > s0:
+            sh.select_local(g, w_shard, seed, step, s0, s1)
+        local = (s0 - st[g], s1 - st[g]) if s1 > s0 else (0, 0)
+        # ... then the particles whose slot is owned by another rank
         ops, recvs, sends = [], [], []
         for h in range(G):
             if h == g:
@@ -320,15 +326,11 @@ class ShardedFilter:
                 recvs.append((r0, r1, buf.cpu() if self.stage else buf))
                 ops.append(dist.P2POp(dist.irecv, recvs[-1][2], h))
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        # the ancestors of the slots that stay on this rank are selected while the exchange is in flight (RCCL works
-        # on a stream of its own; the import below is ordered after it by the wait)
-        s0, s1 = max(lo[g], st[g]), min(lo[g + 1], st[g + 1])
-        if s1 > s0:
-            sh.select_local(g, w_shard, seed, step, s0, s1)
         if self.overlap and device_handover and recvs:
-            # leave with the exchange in flight: the library records the slots that still wait for their particles
+            # leave with the exchange in flight (RCCL works on a stream of its own): the library records the slots that
+            # still wait for their particles
             sh.finish(want_flags=False)
-            self._pending = (reqs, recvs, (s0 - st[g], s1 - st[g]) if s1 > s0 else (0, 0), sends)
+            self._pending = (reqs, recvs, local, sends)
         else:
             for req in reqs:
                 req.wait()

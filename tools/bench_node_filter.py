@@ -4,8 +4,8 @@ K updates on the observations of bench.py.  With fewer devices than shards the s
 box can show: the phases' own cost, not the transfers over xGMI).
 
 usage: bench_node_filter.py [particles] [shards] [updates]"""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import epidemicmodeling_amd as em
 from epidemicmodeling_amd.distributed import NodeFilter
