@@ -210,7 +210,10 @@ int epi_pf_update(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t see
  *                       output-slot range [lo[g], lo[g+1]) whose ancestors live
  *                       in shard g (host arithmetic, identical on every rank).
  *   4. epi_pf_select_local : ancestors for the part of that range this shard
- *                       also owns (no data movement);
+ *                       also owns (no data movement).  Called before the first
+ *                       export of an update it also leaves the cumulative weights
+ *                       that the exports search (one pass instead of two; any
+ *                       order of the calls of this step gives the same result);
  *      epi_pf_export  : for a part owned by another shard, the resampled
  *                       particles themselves, packed as int32[rows][count];
  *      epi_pf_import  : place a packed block received from another shard.
