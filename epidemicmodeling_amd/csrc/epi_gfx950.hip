@@ -160,6 +160,7 @@ struct epi_belief {
     // bookkeeping of the phased update: columns that received an ancestor in the update in progress, columns that
     // still wait for one after epi_pf_finish, columns the step of the next update has covered so far
     bool cum_ready = false;             // the update in progress has written its cumulative weights (over the log weights)
+    bool flags_delivered = false;       // ... and handed its step flags over with the weight totals (device flags are clear again)
     std::vector<Span> filled, unfilled, done;
     double part_a = 0.0; int64_t part_o = 0;                // arguments of the first epi_pf_predict_part of an update
 };
@@ -930,22 +931,19 @@ __device__ __forceinline__ unsigned long long quantize(double lw, double lwmax, 
 __device__ __forceinline__ double lwmax_decode(unsigned long long bits) { return bits ? order_decode(bits) : -__builtin_inf(); }
 // the device-side hand-over of the phased update: local maximum out, global maximum in, local totals out
 __global__ void k_scal_export_lwmax(const DevScalars* s, double* out) { out[0] = lwmax_decode(s->lwmax_bits); }
-__global__ void k_scal_import_lwmax(DevScalars* s, const double* in) { s->lwmax = in[0]; }
-__global__ void k_scal_export_totals(const DevScalars* s, double* out)
-{
-    out[0] = (double)s->w_local; out[1] = s->sumsq; out[2] = (double)s->flags; out[3] = s->lwmax;
-}
-__global__ void k_scal_set_offsets(DevScalars* s, unsigned long long off, unsigned long long total) { s->w_off = off; s->w_total = total; }
+// (global maximum in and local totals out ride on k_wsum and k_wscan)
 
 // LOCAL: the population lives on this device alone, so the local maximum log weight (still coded, as the step kernel's
-// atomics left it) is the global one; otherwise the caller has installed the global maximum in scal->lwmax.
+// atomics left it) is the global one; otherwise the global maximum is read from lwmax_src (device memory, where the
+// caller's exchange left it) or, when that is null, from scal->lwmax, where the caller has installed it.
 template <bool LOCAL>
 __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restrict__ lw, const DevScalars* __restrict__ scal, int F,
-                                               unsigned long long* __restrict__ blocksum, double* __restrict__ blocksq)
+                                               unsigned long long* __restrict__ blocksum, double* __restrict__ blocksq,
+                                               const double* __restrict__ lwmax_src = nullptr)
 {
     __shared__ unsigned long long s_sum[TPB / 64];
     __shared__ double s_sq[TPB / 64];
-    const double lwmax = LOCAL ? lwmax_decode(scal->lwmax_bits) : scal->lwmax;
+    const double lwmax = LOCAL ? lwmax_decode(scal->lwmax_bits) : (lwmax_src ? *lwmax_src : scal->lwmax);
     const double scale = u2d((uint64_t)(F + 1023) << 52);
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     unsigned long long sum = 0ULL;
@@ -972,8 +970,12 @@ __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restric
 // one workgroup: exclusive scan of blocksum in place, totals to scal; also the update's housekeeping: the list of long
 // child ranges is emptied for the scatter kernel that follows, and the code of the maximum log weight is cleared for
 // the next update (local: the maximum is decoded first and the local weight total is the global one)
+// lwmax_src / totals_out (both or neither): the device-memory hand-over of a sharded update -- the global maximum is
+// installed in scal for the kernels that follow, and {local weight total, sum of squares, step flags, global maximum} go
+// out as four doubles; the flags have then been delivered and are cleared.
 __global__ __launch_bounds__(1024) void k_wscan(int64_t nb, unsigned long long* __restrict__ blocksum, const double* __restrict__ blocksq,
-                                                DevScalars* __restrict__ scal, unsigned long long* __restrict__ big_count, int local)
+                                                DevScalars* __restrict__ scal, unsigned long long* __restrict__ big_count, int local,
+                                                const double* __restrict__ lwmax_src = nullptr, double* __restrict__ totals_out = nullptr)
 {
     __shared__ unsigned long long s_w[16];
     __shared__ unsigned long long s_carry;
@@ -1012,6 +1014,12 @@ __global__ __launch_bounds__(1024) void k_wscan(int64_t nb, unsigned long long* 
         if (local) { scal->lwmax = lwmax_decode(scal->lwmax_bits); scal->w_off = 0ULL; scal->w_total = s_carry; }
         scal->lwmax_bits = 0ULL;
         *big_count = 0ULL;
+        if (totals_out) {
+            const double g = *lwmax_src;
+            scal->lwmax = g;
+            totals_out[0] = (double)s_carry; totals_out[1] = q; totals_out[2] = (double)scal->flags; totals_out[3] = g;
+            scal->flags = 0u;
+        }
     }
 }
 
@@ -1054,10 +1062,9 @@ __global__ __launch_bounds__(TPB) void k_wcum(int64_t n, double* __restrict__ lw
 //   T_m = fl(fl(m + u) * fl(W / n_total)); ancestor = #{ i : C_i <= floor(T_m) }
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int64_t find_ancestor(const unsigned long long* __restrict__ cum, int64_t n_local,
-                                                 const DevScalars* __restrict__ scal, int64_t n_total, double u, int64_t m_global,
+                                                 unsigned long long W, unsigned long long off, int64_t n_total, double u, int64_t m_global,
                                                  int64_t slot0)
 {
-    const unsigned long long W = scal->w_total;
     if (W == 0ULL) {                        // every weight zero: keep the particle in place
         int64_t i = m_global - slot0;
         return i < 0 ? 0 : (i >= n_local ? n_local - 1 : i);
@@ -1065,7 +1072,6 @@ __device__ __forceinline__ int64_t find_ancestor(const unsigned long long* __res
     const double stepw = (double)W / (double)n_total;
     const double Tm = ((double)m_global + u) * stepw;
     unsigned long long tq = (unsigned long long)__builtin_floor(Tm);
-    const unsigned long long off = scal->w_off;
     tq = tq > off ? tq - off : 0ULL;
     int64_t lo = 0, hi = n_local;           // first index with cum > tq
     while (lo < hi) {
@@ -1312,12 +1318,12 @@ __global__ __launch_bounds__(TPB) void k_scatter_big(const unsigned long long* _
 
 // resampled particles of slots [slot_begin, slot_begin + count) packed as dst[row * count + j]
 __global__ __launch_bounds__(TPB) void k_export(int64_t count, int64_t slot_begin, int64_t slot0, const unsigned long long* __restrict__ cum,
-                                                 int64_t n_local, const DevScalars* __restrict__ scal, int64_t n_total, double u,
+                                                 int64_t n_local, unsigned long long W, unsigned long long off, int64_t n_total, double u,
                                                  const int32_t* __restrict__ src, int64_t stride, int rows, int32_t* __restrict__ dst)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= count) return;
-    const int64_t a = find_ancestor(cum, n_local, scal, n_total, u, slot_begin + j, slot0);
+    const int64_t a = find_ancestor(cum, n_local, W, off, n_total, u, slot_begin + j, slot0);
     for (int r = 0; r < rows; r++) dst[(int64_t)r * count + j] = src[(int64_t)r * stride + a];
 }
 
@@ -2777,13 +2783,15 @@ static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, do
     return EPI_OK;
 }
 
-static int launch_weigh(epi_ctx* c, epi_belief* b)
+// d_lwmax_global / d_totals: the device-memory hand-over (both, or neither: the host has installed the maximum in scal)
+static int launch_weigh(epi_ctx* c, epi_belief* b, const double* d_lwmax_global = nullptr, double* d_totals = nullptr)
 {
     b->halo_used = 0;                   // the halo of the buffer this update writes starts empty
     b->filled.clear();
-    k_wsum<false><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, b->blocksq);
-    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, b->scal, b->big, 0);
+    k_wsum<false><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, b->blocksq, d_lwmax_global);
+    k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, b->scal, b->big, 0, d_lwmax_global, d_totals);
     HIPCHECK(hipGetLastError());
+    b->flags_delivered = d_totals != nullptr;
     b->cum_ready = false;               // written by whichever comes first: the ancestors of the owned slots, or an export
     return EPI_OK;
 }
@@ -3120,11 +3128,8 @@ int epi_pf_weigh_dev(epi_ctx* c, epi_belief* b, const double* d_lwmax_global, do
     if (!d_lwmax_global || !d_totals) return fail(EPI_EINVAL, "epi_pf_weigh_dev: NULL device pointer");
     if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh_dev: call epi_pf_predict_dev first");
     HIPCHECK(hipSetDevice(c->device));
-    k_scal_import_lwmax<<<1, 1, 0, c->stream>>>(b->scal, d_lwmax_global);
-    rc = launch_weigh(c, b);
+    rc = launch_weigh(c, b, d_lwmax_global, d_totals);
     if (rc) return rc;
-    k_scal_export_totals<<<1, 1, 0, c->stream>>>(b->scal, d_totals);
-    HIPCHECK(hipGetLastError());
     b->phase = PH_WEIGHED;
     return EPI_OK;
 }
@@ -3158,15 +3163,6 @@ int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, 
     return EPI_OK;
 }
 
-static int set_offsets(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard)
-{
-    unsigned long long off = 0ULL, total = 0ULL;
-    for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
-    k_scal_set_offsets<<<1, 1, 0, c->stream>>>(b->scal, off, total);
-    HIPCHECK(hipGetLastError());
-    return EPI_OK;
-}
-
 int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
                         int64_t slot_begin, int64_t slot_end)
 {
@@ -3177,8 +3173,6 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
         return fail(EPI_EINVAL, "epi_pf_select_local: slots [%lld, %lld) not owned by this shard", (long long)slot_begin, (long long)slot_end);
     if (slot_begin == slot_end) return EPI_OK;
     HIPCHECK(hipSetDevice(c->device));
-    rc = set_offsets(c, b, G, shard, w_shard);
-    if (rc) return rc;
     const double u = resample_offset(seed, step);
     unsigned long long off = 0ULL, total = 0ULL;
     for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
@@ -3197,15 +3191,15 @@ int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w
     if (slot_begin > slot_end || slot_begin < 0 || slot_end > b->n_total || !dev_buf) return fail(EPI_EINVAL, "epi_pf_export: bad slot range or NULL buffer");
     if (slot_begin == slot_end) return EPI_OK;
     HIPCHECK(hipSetDevice(c->device));
-    rc = set_offsets(c, b, G, shard, w_shard);
-    if (rc) return rc;
     rc = ensure_cum(c, b);
     if (rc) return rc;
     const double u = resample_offset(seed, step);
     const int64_t count = slot_end - slot_begin;
+    unsigned long long off = 0ULL, total = 0ULL;
+    for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
     // the propagated particles of this update live in the buffer k_step wrote
     k_export<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, slot_begin, b->slot0, reinterpret_cast<const unsigned long long*>(b->lw),
-                                                                             b->n, b->scal, b->n_total, u, b->buf[b->cur ^ 1], b->stride, b->rows,
+                                                                             b->n, total, off, b->n_total, u, b->buf[b->cur ^ 1], b->stride, b->rows,
                                                                              static_cast<int32_t*>(dev_buf));
     HIPCHECK(hipGetLastError());
     if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
@@ -3262,7 +3256,7 @@ int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
     if (flags) {
         rc = fetch_flags(c, b->scal, flags, true);
         if (rc) return rc;
-    } else HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
+    } else if (!b->flags_delivered) HIPCHECK(hipMemsetAsync(&b->scal->flags, 0, sizeof(unsigned int), c->stream));
     if (!c->external) HIPCHECK(hipStreamSynchronize(c->stream));
     b->cur ^= 1; b->has_anc = true;
     // owned slots that neither epi_pf_select_local nor epi_pf_import has given an ancestor wait for epi_pf_import_late

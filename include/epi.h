@@ -225,7 +225,8 @@ int epi_pf_weigh(epi_ctx *ctx, epi_belief *b, double lwmax_global, uint64_t *w_l
 /* The first two phases without a host round trip, for a host that runs the exchange on the same HIP
  * stream (epi_ctx_set_stream): the local maximum is written to, the global maximum read from, device
  * memory, and d_totals receives {local weight total, local sum of squares, local flags, global maximum}
- * as four doubles (totals are < 2^53, exact). */
+ * as four doubles (totals are < 2^53, exact).  The flags are delivered there: epi_pf_finish after epi_pf_weigh_dev
+ * has none left to report. */
 int epi_pf_predict_dev(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step,
                        double *d_lwmax_local /* device, 1 double */);
 int epi_pf_weigh_dev(epi_ctx *ctx, epi_belief *b, const double *d_lwmax_global /* device, 1 double */,
