@@ -296,6 +296,10 @@ function GPUNodeFilter(m::CovidPOMDP, n::Integer; devices::Vector{<:Integer} = c
 end
 ParticleFilters.n_particles(f::GPUNodeFilter) = f.n
 
+# An update normally returns while the particles that change shard are still on their way, and the next one steps
+# around them; overlap!(f, false) makes every update place them before it returns.
+overlap!(f::GPUNodeFilter, on::Bool) = (check(ccall((:epi_mctx_set_overlap, LIBEPI), Cint, (Ptr{Cvoid}, Cint), f.h, on)); f)
+
 function initialbelief(f::GPUNodeFilter; μ = 10_000.0, σ = 5_000.0)
     check(ccall((:epi_mctx_init_normal, LIBEPI), Cint, (Ptr{Cvoid}, Float64, Float64, UInt64), f.h, μ, σ, f.seed))
     f
