@@ -3163,7 +3163,7 @@ int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, 
     return EPI_OK;
 }
 
-int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
+static int epi_pf_select_local_body(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
                         int64_t slot_begin, int64_t slot_end)
 {
     int rc = belief_check(b, "epi_pf_select_local");
@@ -3180,6 +3180,12 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
     if (rc) return rc;
     b->filled.emplace_back(slot_begin - b->slot0, slot_end - b->slot0);
     return EPI_OK;
+}
+
+int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
+                        int64_t slot_begin, int64_t slot_end)
+{
+    return guarded("epi_pf_select_local", [&]() -> int { return epi_pf_select_local_body(c, b, G, shard, w_shard, seed, step, slot_begin, slot_end); });
 }
 
 int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
@@ -3229,7 +3235,7 @@ static int import_block(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t s
     return EPI_OK;
 }
 
-int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
+static int epi_pf_import_body(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
 {
     int rc = belief_check(b, "epi_pf_import");
     if (rc) return rc;
@@ -3238,7 +3244,12 @@ int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_en
     return import_block(c, b, slot_begin, slot_end, dev_buf, false, "epi_pf_import");
 }
 
-int epi_pf_import_late(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
+int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
+{
+    return guarded("epi_pf_import", [&]() -> int { return epi_pf_import_body(c, b, slot_begin, slot_end, dev_buf); });
+}
+
+static int epi_pf_import_late_body(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
 {
     int rc = belief_check(b, "epi_pf_import_late");
     if (rc) return rc;
@@ -3247,7 +3258,12 @@ int epi_pf_import_late(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t sl
     return import_block(c, b, slot_begin, slot_end, dev_buf, true, "epi_pf_import_late");
 }
 
-int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
+int epi_pf_import_late(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
+{
+    return guarded("epi_pf_import_late", [&]() -> int { return epi_pf_import_late_body(c, b, slot_begin, slot_end, dev_buf); });
+}
+
+static int epi_pf_finish_body(epi_ctx* c, epi_belief* b, uint32_t* flags)
 {
     int rc = belief_check(b, "epi_pf_finish");
     if (rc) return rc;
@@ -3264,6 +3280,11 @@ int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
     b->filled.clear();
     b->phase = b->unfilled.empty() ? PH_IDLE : PH_PENDING;
     return EPI_OK;
+}
+
+int epi_pf_finish(epi_ctx* c, epi_belief* b, uint32_t* flags)
+{
+    return guarded("epi_pf_finish", [&]() -> int { return epi_pf_finish_body(c, b, flags); });
 }
 
 // ---- summaries ---------------------------------------------------------------------
