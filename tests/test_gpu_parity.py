@@ -1317,3 +1317,38 @@ def test_config3_eight_shards_full_size_equal_the_single_update():
         sl = slice(starts[g], starts[g + 1])
         assert (s[sl] == S[sl]).all() and (i[sl] == I[sl]).all() and (r[sl] == R[sl]).all() and (t[sl] == T[sl]).all()
     node.close()
+
+
+def test_entry_points_that_only_hosts_outside_the_package_call():
+    """epi_pf_update_async + epi_pf_collect (bench.py's loop) against epi_pf_update; the event timing hooks; the shape
+    and stream queries."""
+    from epidemicmodeling_amd.odefit import Ensemble
+    from epidemicmodeling_amd.distributed import NodeFilter
+    pomdp = em.make_pomdp(LOD=5)
+    n = 5000
+    b1, b2 = em.initialbelief(pomdp, n, seed=SEED), em.initialbelief(pomdp, n, seed=SEED)
+    ctx, lib = b1.ctx, b1.ctx.lib
+    assert lib.epi_ctx_stream(ctx.handle) is not None                     # the context's own stream
+    check(lib.epi_ctx_timing(ctx.handle, 1))
+    for step, o in enumerate((9000, 8500, 9500)):
+        check(lib.epi_pf_update_async(ctx.handle, b1.handle, 0.2, o, SEED, step))
+    ll1, ess1, fl1 = C.c_double(), C.c_double(), C.c_uint32()
+    check(lib.epi_pf_collect(ctx.handle, b1.handle, C.byref(ll1), C.byref(ess1), C.byref(fl1)))
+    tot, cnt = C.c_double(), C.c_int64()
+    check(lib.epi_ctx_timing_read(ctx.handle, C.byref(tot), C.byref(cnt)))
+    check(lib.epi_ctx_timing(ctx.handle, 0))
+    assert cnt.value == 3 and 0.0 < tot.value < 1000.0
+    ll2, ess2, fl2 = C.c_double(), C.c_double(), C.c_uint32()
+    for step, o in enumerate((9000, 8500, 9500)):
+        check(lib.epi_pf_update(ctx.handle, b2.handle, 0.2, o, SEED, step, C.byref(ll2), C.byref(ess2), C.byref(fl2)))
+    assert (ll1.value, ess1.value, fl1.value) == (ll2.value, ess2.value, fl2.value)
+    _eq(b1.download(), b2.download())
+    assert 0.0 < lib.epi_last_predict_ms(ctx.handle) < 1000.0             # the last (untimed) update's step kernel
+    ens = Ensemble(b1, 7, 0.3, seed=5)
+    en, eT = C.c_int64(), C.c_int()
+    check(lib.epi_ensemble_shape(ens._h, C.byref(en), C.byref(eT)))
+    assert (en.value, eT.value) == (n, 7)
+    ens.close()
+    f = NodeFilter(pomdp, 1234, [0, 0, 0], seed=SEED)
+    assert lib.epi_mctx_shards(f._h) == 3 and lib.epi_mctx_size(f._h) == 1234
+    f.close(); b1.close(); b2.close()
