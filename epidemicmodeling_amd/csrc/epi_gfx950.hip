@@ -3366,7 +3366,11 @@ static int enqueue_qsel_passes(epi_ctx* c, int64_t n, const int32_t* dv)
     QselState* const st = reinterpret_cast<QselState*>(c->d_qsel + QSEL_HIST_BYTES);
     int64_t g = ceil_div(n, (int64_t)QTPB * 16);                       // two trips of eight values per thread; few workgroups (ticket)
     g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-    for (int pass = 0; pass < QSEL_MAX_PASSES; pass++)
+    // an infected total is at most the population N: the first window spans at most bits(N) bits, each pass resolves 11
+    int bits = 0;
+    while (bits < 31 && (c->P.N >> bits) != 0) bits++;
+    const int passes = bits <= QSEL_LOG_BINS ? 1 : (bits <= 2 * QSEL_LOG_BINS ? 2 : QSEL_MAX_PASSES);
+    for (int pass = 0; pass < passes; pass++)
         k_qsel_pass<<<dim3((unsigned)g), dim3(QTPB), 0, c->stream>>>(n, dv, st, dh);
     HIPCHECK(hipGetLastError());
     return EPI_OK;
@@ -3442,7 +3446,7 @@ __global__ __launch_bounds__(64) void k_day_pack(unsigned char* __restrict__ rec
     if (threadIdx.x == 0) {
         h->r = *r_dev; h->o = *o_dev;
         h->lwmax = scal_b->lwmax; h->sumsq = scal_b->sumsq; h->w_total = scal_b->w_total;
-        h->flags = scal_b->flags | scal_t->flags; h->pad = 0u;
+        h->flags = scal_b->flags | scal_t->flags; h->pad = nq ? (unsigned int)st->W : 0u;   // pad: bits the selection left undecided (0)
         scal_b->flags = 0u; scal_t->flags = 0u;
         int32_t tot = 0;
         for (int i = 0; i < H; i++) tot += truth[(int64_t)(2 + i) * tstride];
@@ -3521,6 +3525,7 @@ int epi_closed_loop_days(epi_ctx* c, epi_belief* truth, epi_belief* b, int ndays
         for (int d = 0; d < ndays; d++) {
             const DayHead* e = reinterpret_cast<const DayHead*>(h + rec * (size_t)d);
             const long long* tail = reinterpret_cast<const long long*>(h + rec * (size_t)d + sizeof(DayHead));
+            if (e->pad != 0u) return fail(EPI_ESTATE, "epi_closed_loop_days: day %d: selection did not finish (an infected total above the population?)", d);
             if (o_out) o_out[d] = e->o;
             if (r_out) r_out[d] = e->r;
             if (true_sir) { true_sir[3 * d] = e->S; true_sir[3 * d + 1] = e->sumI; true_sir[3 * d + 2] = e->R; }
