@@ -16,6 +16,13 @@ def _env(**extra):
     return env
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _json_line(out: bytes):
     lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out
@@ -33,7 +40,7 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
 
 def test_bench_refuses_a_process_group_of_the_wrong_size():
     # a launcher that started one rank although --gpus says two: every rank must fail, nothing may be printed
-    env = _env(EPI_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = _env(EPI_BENCH_BACKEND="gloo", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0
