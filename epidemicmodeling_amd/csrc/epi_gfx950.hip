@@ -105,6 +105,7 @@ struct DevScalars {
     unsigned int flags;
     unsigned int pad;
 };
+static_assert(ZIG_N <= 256, "one thread per strip copies the table");
 static_assert(sizeof(DevScalars) <= 256, "the scalars of an update live in a 256-byte slot");
 
 struct epi_ctx {
@@ -331,10 +332,10 @@ __global__ __launch_bounds__(TPB, THREAD_WAVES) void k_step(const StepArgs A, co
             InjectedDraws d{A.inj_sympt, A.inj_pos, A.inj_gam, A.n, m};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else if constexpr (MODE == MODE_RECORD) {
-            RecordingDraws d{PhiloxDraws{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0.f, 0u}, A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
+            RecordingDraws d{PhiloxDraws{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), A.screen != 0, Dp, 0u, 0u}, A.rec_sympt, A.rec_pos, A.rec_gam, A.n, m};
             res = particle_step(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         } else {
-            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), SCREEN ? true : A.screen != 0, Dp, 0.f, 0u};
+            PhiloxDraws d{rng_make(A.seed, A.slot0 + (uint64_t)m, A.step), SCREEN ? true : A.screen != 0, Dp, 0u, 0u};
             res = particle_step<DELAY>(P, A.in, A.in_stride, src, A.out, A.out_stride, m, a, d, A.pos_out, A.n);
         }
         flags = res.flags;
@@ -425,9 +426,9 @@ __global__ __launch_bounds__(64) void k_step_one(const StepArgs A, const DevPara
     double gval = 0.0;
     if (act) {
         if (i >= 1) A.out[(int64_t)(2 + i) * A.out_stride] = seedling;
-        float zf; uint32_t wu;
-        gamma_first(g, (uint32_t)i, zf, wu);
-        gval = gamma_draw(P.k[i] * (double)seedling, P.theta[i], zf, wu, g, (uint32_t)i, screen);   // simulate.jl:40, init.jl:71-78
+        uint32_t wz, wu;
+        gamma_first(g, (uint32_t)i, wz, wu);
+        gval = gamma_draw(P.k[i] * (double)seedling, P.theta[i], wz, wu, &Dp->zig, g, (uint32_t)i, screen);   // simulate.jl:40, init.jl:71-78
     }
     int32_t r_sum = r_add, o_sum = pos, pre_sum = I_pre, post_sum = (act && i >= 1) ? seedling : 0;
     for (int d = 32; d >= 1; d >>= 1) {
@@ -496,6 +497,23 @@ __device__ __forceinline__ double sqrt_unscaled(double x)
     return x == 0.0 ? x : g3;
 }
 
+// a rejection draw from attempt 0 on in one thread (a full retry queue)
+__device__ __noinline__ int32_t btrs_from0(int32_t n, const BtrsBin B, const LfTable lf, bool screen, const Rng g, int j, uint32_t bin)
+{
+    uint32_t w[4];
+    rng_block(g, K_BINOM0, bin, 0, w);
+    const BtrsConsts C = btrs_consts(n, B);
+    const int32_t k = btrs_attempt(C, B.lpq, lf, screen, j ? w[2] : w[0], j ? w[3] : w[1]);
+    return k >= 0 ? k : btrs_finish(C, B.lpq, lf, screen, g, j ? K_POS : K_SYMPT, bin, 1u);
+}
+// an infection term from attempt 0 on in one thread
+__device__ __noinline__ double gamma_from0(double shape, double scale, const ZigTable* __restrict__ Z, const Rng g, uint32_t term, bool screen)
+{
+    uint32_t wz, wu;
+    gamma_first(g, term, wz, wu);
+    return gamma_draw(shape, scale, wz, wu, Z, g, term, screen);
+}
+
 // push `entry` for every lane that wants to (one LDS atomic per wave); false = queue full
 __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn)
 {
@@ -544,6 +562,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     unsigned short* q1 = q0 + QCAP;
     unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP);                 // qn[0..2]: entry counts, rotating (+ 1 pad)
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
+    ZigEntry* ztab = reinterpret_cast<ZigEntry*>(s_max + CTPB / 64);               // [ZIG_N]: strips of the normal generator
 
     const int tid = threadIdx.x;
     const int64_t base = ((int64_t)xcd_tile() + A.block0) * CTPB;
@@ -569,7 +588,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[tid], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
-    // the cleared counts must be visible before any wave pushes to the queue (after phase B): the barrier stands here,
+    if (tid < ZIG_N) ztab[tid] = Dp->zig.e[tid];
+    // the cleared counts and the strips must be visible before any wave pushes to the queue (after phase B): the barrier stands here,
     // where the waves of the workgroup still run together, and not between phases A and B, which only exchange data
     // within a thread
     __syncthreads();
@@ -612,9 +632,11 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
-    // ---- B: attempt 0 of both binomials of every bin --------------------------------
-    // rejected draws are remembered in a bit mask (bit 2 i + j) and queued in one go after the loop: one
-    // prefix sum and one LDS atomic per wave instead of one per bin
+    // ---- B: the table-free part of attempt 0 of both binomials of every bin --------------------------------
+    // A rejection draw is settled here when its candidate falls inside the squeeze region (about six in seven);
+    // every other draw is remembered in a bit mask (bit 2 i + j) and queued in one go after the loop: one prefix sum
+    // and one LDS atomic per wave instead of one per bin.  The queued draws repeat attempt 0 in full in round 1 of
+    // phase C (the words are a function of the counter: nothing has to be kept).
     unsigned long long fm0 = 0ULL, fm1 = 0ULL;                                     // bins 0..31 / 32..63
 #pragma unroll 1
     for (int i = 0; i < H; i++) {
@@ -631,18 +653,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 int32_t x;
                 const BinConsts bc = Dp->bc[j][i];                                 // wave-uniform: scalar loads
                 // all of the record before the first branch: the loads go out together and are waited for once
-                // (left alone, each is sunk to its first use and waited for there: classification, threshold, rest)
-                asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.pp), "s"(bc.lpq), "s"(bc.lf_t), "s"(bc.lf_n));
+                asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2));
                 const int cls = binom_classify_rec(bc, n, x);
                 const bool flip = bc.flip != 0;
                 bool fail = false;
                 if (cls == BINOM_INVERSION) x = binom_inversion(n, bc.lnq, bc.sr, wa);
                 else if (cls == BINOM_REJECTION) {
-                    BtrsConsts C;
-                    x = btrs_try(C, n, bc.pp, bc.lpq, LfTable{bc.lf_t, bc.lf_n}, screen, wa, wb);
-                    fail = x < 0;
+                    const BtrsConsts C = btrs_consts(n, bc.btrs());
+                    fail = !btrs_fast(C, wa, wb, x);
                 }
-                const int32_t res = fail ? n : (flip ? n - x : x);                 // a rejected draw keeps n for its retry
+                const int32_t res = fail ? n : (flip ? n - x : x);                 // an open draw keeps n for phase C
                 if (j) nn.y = res; else nn.x = res;
                 failbits |= (unsigned int)fail << j;
             }
@@ -674,7 +694,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14));
                 else {                                                              // queue full: finish here
                     const int32_t n = slot_words[(i * CTPB + tid) * 2 + j];
-                    const int32_t k = btrs_finish(btrs_consts(n, Dp->pp[j][i], Dp->lpq[j][i], Dp->lf, screen), g, j ? K_POS : K_SYMPT, (uint32_t)i, 1u);
+                    const int32_t k = btrs_from0(n, Dp->bc[j][i].btrs(), Dp->lf, screen, g, j, (uint32_t)i);
                     slot_words[(i * CTPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
                 }
                 pos++;
@@ -682,14 +702,15 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
-    // ---- C: binomial retry rounds ------------------------------------------------------
+    // ---- C: binomial rounds ----------------------------------------------------------------
+    // Round r runs attempt r - 1 of every queued draw in full (round 1 repeats attempt 0 with its acceptance test).
     // One barrier per round: round r reads the entries of queue (r-1) mod 2, counted in qn[(r-1) mod 3], and pushes
     // its rejected draws to queue r mod 2, counted in qn[r mod 3]; thread 0 clears qn[(r+1) mod 3] for the round after
     // (it was last read in round r-1, before this round's barrier).
     {
         int cur = 0;                                                               // (round - 1) mod 3
 #pragma unroll 1
-        for (uint32_t round = 1; round < BINOM_MAX_ATTEMPTS; round++) {
+        for (uint32_t round = 1; round <= BINOM_MAX_ATTEMPTS; round++) {
             __syncthreads();
             const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
             if (cnt == 0u) break;
@@ -697,23 +718,28 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
             unsigned short* qnext = (round & 1u) ? q1 : q0;
+            const uint32_t att = round - 1u;
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
                 const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
                 const BinConsts* __restrict__ bp = &Dp->bc[j][i];                  // the lane's record: adjacent loads
-                const double pp = bp->pp, lpq = bp->lpq;
+                const BtrsBin B = bp->btrs();
                 const bool flip = bp->flip != 0;                                   // a queued draw is a rejection draw
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wa, wb;
-                retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, round, wa, wb);
-                BtrsConsts C;
-                int32_t k = btrs_try(C, n, pp, lpq, Dp->lf, screen, wa, wb);
+                if (att == 0u) {
+                    uint32_t w[4];
+                    rng_block(gt, K_BINOM0, (uint32_t)i, 0, w);
+                    wa = j ? w[2] : w[0]; wb = j ? w[3] : w[1];
+                } else retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, att, wa, wb);
+                const BtrsConsts C = btrs_consts(n, B);
+                int32_t k = btrs_attempt(C, B.lpq, Dp->lf, screen, wa, wb);
                 const bool fail = k < 0;
                 // after the last round nothing reads the queue: a draw rejected there ends as in btrs_finish
-                const bool pushed = round + 1u < BINOM_MAX_ATTEMPTS && q_push(fail, entry, qnext, &qn[nxt]);
-                if (fail && !pushed) k = btrs_finish(C, gt, j ? K_POS : K_SYMPT, (uint32_t)i, round + 1u);
+                const bool pushed = round < BINOM_MAX_ATTEMPTS && q_push(fail, entry, qnext, &qn[nxt]);
+                if (fail && !pushed) k = btrs_finish(C, B.lpq, Dp->lf, screen, gt, j ? K_POS : K_SYMPT, (uint32_t)i, att + 1u);
                 if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
             }
             cur = nxt;
@@ -722,12 +748,12 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }                           // the count a slower thread may still be reading is zero already
     __syncthreads();
 
-    // ---- D: isolation bookkeeping and attempt 0 of the gamma terms -------------------------
+    // ---- D: isolation bookkeeping and the table-and-squeeze part of attempt 0 of the gamma terms ----------------
     // iteration `it` handles bin (it == 0 ? H-1 : it-1), whose survivors seed infection term `it`
-    // (the circular shift of simulate.jl:145)
+    // (the circular shift of simulate.jl:145).  A term is settled here when its normal comes from the inside of a
+    // strip and the squeeze accepts it; the others are queued and repeat attempt 0 in full in round 1 of phase E.
     int32_t sum_inf = 0;
-    float z_odd = 0.f;              // second normal / word of the pair block, for the odd term
-    uint32_t w_odd = 0u;
+    uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
     int32_t I_next = active ? ld_in(1 + H) : 0;                                    // bin H-1; loads run one bin ahead
     int2 sp_next = slots[(H - 1) * CTPB + tid];                                    // so does the read of the bin's slot
 #pragma unroll 1
@@ -760,35 +786,34 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (it == 0) R += Ii;                                                  // simulate.jl:144
             else { st_out(2 + it, Ii); sum_inf += Ii; }                            // simulate.jl:145
             const double shape = k_it * (double)Ii;                                // init.jl:71-78
-            float zf = z_odd;
-            uint32_t wu = w_odd;
+            uint32_t wz = z_odd, wu = w_odd;
             if ((it & 1) == 0) {                                                   // an even term generates the block of its pair
                 uint32_t w[4];
-                float z0;
                 rng_block(g, K_GAMMA, (uint32_t)it >> 1, 0, w);
-                box_muller(w[0], w[1], z0, z_odd);
-                zf = z0; wu = w[2]; w_odd = w[3];
+                wz = w[0]; z_odd = w[1]; wu = w[2]; w_odd = w[3];
             }
             if (gamma_is_zero(shape)) gslots[i * CTPB + tid] = 0.0;
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
+                float xf;
                 double v;
-                if (gamma_attempt(G, zf, wu, v)) gslots[i * CTPB + tid] = gamma_finish(G, v, theta_it, g, (uint32_t)it);
+                const bool inside = zig_fast(wz, ztab[wz & 127u], xf);
+                if (gamma_fast(G, xf, wu, v) && inside) gslots[i * CTPB + tid] = gamma_finish(G, v, theta_it, g, (uint32_t)it);
                 else { slots[i * CTPB + tid] = make_int2(Ii, 0); gfail = true; }
             }
         }
         const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[0]);
         if (gfail && !gpushed) {
             const int32_t Ii = slots[i * CTPB + tid].x;
-            gslots[i * CTPB + tid] = gamma_finish_from(gamma_consts(P.k[it] * (double)Ii, screen), P.theta[it], g, (uint32_t)it, 1u);
+            gslots[i * CTPB + tid] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, g, (uint32_t)it, screen);
         }
     }
 
-    // ---- E: gamma retry rounds ---------------------------------------------------------------
+    // ---- E: gamma rounds (round r runs attempt r - 1 in full) ----------------------------------------------------
     {
         int cur = 0;
 #pragma unroll 1
-        for (uint32_t round = 1; round < GAMMA_MAX_ATTEMPTS; round++) {
+        for (uint32_t round = 1; round <= GAMMA_MAX_ATTEMPTS; round++) {
             __syncthreads();
             const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
             if (cnt == 0u) break;
@@ -796,6 +821,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
             unsigned short* qnext = (round & 1u) ? q1 : q0;
+            const uint32_t att = round - 1u;
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
@@ -804,13 +830,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 const int32_t Ii = slots[i * CTPB + t].x;
                 const GammaConsts G = gamma_consts(P.k[it] * (double)Ii, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
-                float zf; uint32_t wu;
-                gamma_retry(gt, (uint32_t)it, round, zf, wu);
+                uint32_t wz, wu;
+                if (att == 0u) gamma_first(gt, (uint32_t)it, wz, wu);
+                else gamma_retry(gt, (uint32_t)it, att, wz, wu);
+                float xf;
+                if (!zig_fast(wz, ztab[wz & 127u], xf)) xf = zig_slow(&Dp->zig, gt, (att << 6) | (uint32_t)it, wz);
                 double v;
-                const bool ok = gamma_attempt(G, zf, wu, v);
-                const bool pushed = round + 1u < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt]);   // as above: gamma_finish_from's ending
+                const bool ok = gamma_attempt(G, xf, wu, v);
+                const bool pushed = round < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt]);   // as above: gamma_finish_from's ending
                 if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
-                else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], gt, (uint32_t)it, round + 1u);
+                else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], &Dp->zig, gt, (uint32_t)it, att + 1u);
             }
             cur = nxt;
         }
@@ -861,7 +890,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     }
 }
 
-static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long); }
+static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry); }
 
 // launch the Philox-driven step with the selected implementation
 template <bool WEIGH>
@@ -1419,14 +1448,15 @@ __global__ __launch_bounds__(TPB) void k_sample_binomial(int64_t count, const in
 }
 
 __global__ __launch_bounds__(TPB) void k_sample_gamma(int64_t count, const double* __restrict__ shape, const double* __restrict__ scale,
-                                                       uint64_t seed, uint32_t step, uint32_t bin, double* __restrict__ out, bool screen)
+                                                       uint64_t seed, uint32_t step, uint32_t bin, double* __restrict__ out, bool screen,
+                                                       const DevParams* __restrict__ Dp)
 {
     const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (j >= count) return;
     Rng g = rng_make(seed, (uint64_t)j, step);
-    float zf; uint32_t wu;
-    gamma_first(g, bin, zf, wu);
-    out[j] = gamma_draw(shape[j], scale[j], zf, wu, g, bin, screen);
+    uint32_t wz, wu;
+    gamma_first(g, bin, wz, wu);
+    out[j] = gamma_draw(shape[j], scale[j], wz, wu, &Dp->zig, g, bin, screen);
 }
 
 // ---------------------------------------------------------------------------
@@ -1928,6 +1958,14 @@ int epi_ctx_create(int device, epi_ctx** out)
             HIPCHECK(hipStreamCreate(&c->own_stream));
             c->stream = c->own_stream;
             HIPCHECK(hipMalloc((void**)&c->d_params, sizeof(DevParams)));
+            {                                   // the strips of the normal generator do not depend on the parameters
+                DevParams* dp = new DevParams();
+                memset(dp, 0, sizeof *dp);
+                zig_build(dp->zig);
+                const hipError_t e = hipMemcpy(c->d_params, dp, sizeof *dp, hipMemcpyHostToDevice);
+                delete dp;
+                HIPCHECK(e);
+            }
             HIPCHECK(hipMalloc((void**)&c->d_lf, sizeof(double) * (size_t)LF_TABLE_N));
             k_lfact_fill<<<dim3(LF_TABLE_N / TPB), dim3(TPB), 0, c->stream>>>(c->d_lf, LF_TABLE_N);
             HIPCHECK(hipGetLastError());
@@ -2003,6 +2041,7 @@ int epi_params_set(epi_ctx* c, const epi_params* p)
         derive_params(dp);
         dp.lf = LfTable{c->d_lf, LF_TABLE_N};
         pack_bin_consts(dp);
+        zig_build(dp.zig);
         HIPCHECK(hipMemcpy(c->d_params, &dp, sizeof dp, hipMemcpyHostToDevice));
         c->P = *p;
         c->have_params = true;
@@ -2489,7 +2528,7 @@ int epi_sample_gamma(epi_ctx* c, int64_t count, const double* shape, const doubl
             return fail(EPI_ENOMEM, "epi_sample_gamma: hipMalloc failed");
         HIPCHECK(hipMemcpyAsync(dk.p, shape, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
         HIPCHECK(hipMemcpyAsync(ds.p, scale, 8 * (size_t)count, hipMemcpyHostToDevice, c->stream));
-        k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>(), g_screen != 0);
+        k_sample_gamma<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, dk.as<double>(), ds.as<double>(), seed, step, bin, dout.as<double>(), g_screen != 0, c->d_params);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpyAsync(out, dout.p, 8 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(hipStreamSynchronize(c->stream));

@@ -20,11 +20,12 @@ namespace epi {
 constexpr uint32_t K_BINOM0 = 0u;  // words 0,1: isolation draw attempt 0; words 2,3: positive-test draw attempt 0
 constexpr uint32_t K_SYMPT  = 1u;  // blk j: isolation attempts 1+2j (words 0,1) and 2+2j (words 2,3)
 constexpr uint32_t K_POS    = 2u;  // same for the positive-test draw
-constexpr uint32_t K_GAMMA  = 3u;  // bin = pair j: attempt 0 of infection term 2j (normal 0, word 2) and of term 2j+1 (normal 1, word 3)
-constexpr uint32_t K_GRETRY = 7u;  // bin = term, blk b: its attempts 1+2b (normal 0, word 2) and 2+2b (normal 1, word 3)
+constexpr uint32_t K_GAMMA  = 3u;  // bin = pair j: attempt 0 of infection term 2j (words 0, 2: normal, uniform) and of term 2j+1 (words 1, 3)
+constexpr uint32_t K_GRETRY = 7u;  // bin = term, blk b: its attempts 1+2b (words 0, 2) and 2+2b (words 1, 3)
 constexpr uint32_t K_BOOST  = 4u;  // word 0: uniform of the shape<1 boost
 constexpr uint32_t K_RESAMP = 5u;  // slot 0: words 0,1 -> 53-bit systematic-resampling offset
 constexpr uint32_t K_INIT   = 6u;  // initial-state generators
+// (8: K_ZIG, the slow path of the normal generator, below)
 
 #define EPI_HD __host__ __device__ __forceinline__
 // rarely executed pieces are kept out of line on the device, where inlining them costs the callers registers
@@ -290,25 +291,12 @@ __device__ __forceinline__ double lfact_of(const LfTable& T, double k)
 static inline double lfact_of(const LfTable&, double k) { return lfact(k); }
 #endif
 
-// The defining acceptance test of the transformed-rejection sampler (Hoermann 1993, step 3):
-//   log(v alpha / (a/us^2 + b))  <=  log f(k) - log f(m)
-//                                 =  [lfact(m) + lfact(n-m)] - [lfact(k) + lfact(n-k)] + (k - m) log(p/q).
-// btrs_lv is the left side (out of line on the device: it runs for a few attempts in a hundred thousand).
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __noinline__
-#else
-static inline
-#endif
-double btrs_lv(double v, double us, double a, double b, double alpha)
-{
-    return s_log(v * alpha / (a / (us * us) + b));
-}
-
 // A Binomial(n, p) draw is split into pieces so that a kernel can either loop over attempts
 // per thread (binomial_draw) or hand failed attempts to other threads:
 //   binom_classify : trivial result / inversion / rejection, and the folded probability
 //   binom_inversion: n min(p,1-p) < 10, one uniform, always completes
-//   btrs_consts    : per-draw constants of the rejection sampler
+//   btrs_bin       : per-probability constants of the rejection sampler
+//   btrs_consts    : its per-draw constants
 //   btrs_attempt   : one attempt from one word pair: accepted k, or -1
 enum { BINOM_DONE = 0, BINOM_INVERSION = 1, BINOM_REJECTION = 2 };
 
@@ -369,193 +357,164 @@ EPI_HD_OUTLINE int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t
     return res;
 }
 
-struct BtrsConsts {
-    double nd, pp, a, b, c, vr, alpha, m, lpq, spq;
-    LfTable lf;
-#ifdef EPI_HAVE_SCREEN
-    double cfl;                     // floor(c), and below its fraction: the k estimate works on small numbers
-    float af, bf, alf, cfr;
-    bool scr;
-#endif
+// ---- the rejection sampler (Hoermann 1993, algorithm BTRS), binary32 hat -------------------------------
+// Per (draw, age bin), functions of the folded probability pp = min(p, 1 - p) alone (tabulated by the kernels):
+//   ppx  = round(pp 2^32)                      the probability in 0.32 fixed point
+//   pq   = (float)(pp (1 - pp))
+//   a0x2 = (float)(2 (-0.0873 + 0.01 pp))
+//   lpq  = s_log(pp / (1 - pp))                binary64
+// Per draw (n >= the inversion threshold), every operation an IEEE binary32 operation in the order written:
+//   spq = sqrt(fl(n) pq),  b = fma(2.53, spq, 1.15),  2a = fma(0.0496, b, a0x2)
+//   c   = n pp + 1/2 and the mode m = floor((n + 1) pp) from the 64-bit products n ppx + 2^31 and (n + 1) ppx:
+//         exact integer parts; the fraction of c keeps its leading 23 bits
+// One attempt from the word pair (wa, wb):
+//   u  = fl((int32) wa) 2^-32 in [-1/2, 1/2],  us = max(1/2 - |u|, 2^-25),  v = fl(wb) 2^-32 in [0, 1]
+//   k  = floor(c) + floor((2a / us + b) u + frac(c)), the inner expression in binary64 from these binary32 values
+//   k outside [0, n]: rejected
+//   us >= 0.07 and (0.92 - v) b >= 4.2 (binary32; Hoermann's v <= v_r without the division): accepted
+//   otherwise accepted iff  log(v alpha / (a / us^2 + b)) <= log f(k) - log f(m)   in binary64, with
+//   alpha = (2.83 + 5.1 / b) spq, the right side from the log factorials as above, v = 0 accepted.
+// The hat only has to dominate: its constants carry three digits in the source and tolerate binary32.  The target
+// ratio f(k) / f(m) is evaluated in binary64 for the exact p, so the accepted k follow Binomial(n, p) up to the
+// resolution of the 32-bit uniform after its conversion to binary32 (relative error of a single probability of
+// the order b 10^-7, of either sign from one k to the next).
+struct BtrsBin {
+    uint32_t ppx;
+    float pq, a0x2;
+    double lpq;
 };
 
-// The constants come in two parts, so that a kernel can start the table loads of the acceptance test between them:
-// btrs_consts_k fills what the candidate k needs, btrs_consts_rest the squeeze bound and the hat's area (one binary32
-// quotient).  lpq = s_log(pp / (1 - pp)) (a per-probability constant, tabulated per age bin by the kernels).
-EPI_HD void btrs_consts_k(BtrsConsts& C, int32_t n, double pp, double lpq, const LfTable& lf, bool screen)
+EPI_HD BtrsBin btrs_bin(double pp)
 {
-    C.nd = (double)n; C.pp = pp; C.lpq = lpq; C.lf = lf;
-    // hat parameters (Hoermann's 3-digit constants tolerate binary32 sqrt / reciprocal)
-    C.spq = (double)sqrt_rn((float)(C.nd * pp * (1.0 - pp)));
-    C.b = 1.15 + 2.53 * C.spq;
-    C.a = -0.0873 + 0.0248 * C.b + 0.01 * pp;
-    C.c = C.nd * pp + 0.5;
-    C.m = __builtin_floor((C.nd + 1.0) * pp);
-#ifdef EPI_HAVE_SCREEN
-    C.scr = screen;
-    C.af = (float)C.a; C.bf = (float)C.b;
-    C.cfl = __builtin_floor(C.c);
-    C.cfr = (float)(C.c - C.cfl);
-#else
-    (void)screen;
-#endif
+    BtrsBin B;
+    B.ppx = (uint32_t)(pp * 4294967296.0 + 0.5);            // pp <= 1/2: fits
+    B.pq = (float)(pp * (1.0 - pp));
+    B.a0x2 = (float)(2.0 * (-0.0873 + 0.01 * pp));
+    B.lpq = (pp > 0.0 && pp < 1.0) ? s_log(pp / (1.0 - pp)) : 0.0;
+    return B;
 }
 
-EPI_HD void btrs_consts_rest(BtrsConsts& C)
-{
-    const double ib = (double)div_rn(1.0f, (float)C.b);
-    C.vr = 0.92 - 4.2 * ib;
-    C.alpha = (2.83 + 5.1 * ib) * C.spq;
-#ifdef EPI_HAVE_SCREEN
-    C.alf = (float)C.alpha;
-#endif
-}
+struct BtrsConsts {
+    float spq, b, a2, cfr;
+    int32_t ci, m, n;
+};
 
-EPI_HD BtrsConsts btrs_consts(int32_t n, double pp, double lpq, const LfTable& lf, bool screen)
+EPI_HD BtrsConsts btrs_consts(int32_t n, const BtrsBin& B)
 {
     BtrsConsts C;
-    btrs_consts_k(C, n, pp, lpq, lf, screen);
-    btrs_consts_rest(C);
+    C.n = n;
+    C.spq = sqrt_rn((float)n * B.pq);
+    C.b = __builtin_fmaf(2.53f, C.spq, 1.15f);
+    C.a2 = __builtin_fmaf(0.0496f, C.b, B.a0x2);
+    const uint64_t prod = (uint64_t)(uint32_t)n * B.ppx + 0x80000000ULL;
+    C.ci = (int32_t)(uint32_t)(prod >> 32);
+    C.cfr = u2f(0x3f800000u | ((uint32_t)prod >> 9)) - 1.0f;
+    C.m = (int32_t)(uint32_t)(((uint64_t)((uint32_t)n + 1u) * B.ppx) >> 32);
     return C;
 }
 
-#ifdef EPI_HAVE_SCREEN
-// Guard band of the binary32 estimate of btrs_lv: its argument carries a relative error below 12 roundings
-// (7e-7), the hardware log2 one ulp of its result, so |estimate - exact| < 1e-6 + 3e-7 |lv|; the band is ten
-// times that (tools/ubench.hip measures the actual worst case).
-constexpr float BTRS_GUARD_REL = 3e-6f, BTRS_GUARD_ABS = 1e-5f;
-__device__ __forceinline__ float btrs_lv_screen(const BtrsConsts& C, double us, double v)
-{
-    const float usf = (float)us;
-    return f_ln((float)v * C.alf * f_rcp(__builtin_fmaf(C.af, f_rcp(usf * usf), C.bf)));
-}
-#endif
+EPI_HD float btrs_u(uint32_t wa) { return (float)(int32_t)wa * 0x1p-32f; }
+EPI_HD float btrs_us(float u) { return __builtin_fmaxf(0.5f - __builtin_fabsf(u), 0x1p-25f); }
+EPI_HD float btrs_v(uint32_t wb) { return (float)wb * 0x1p-32f; }
 
-// right side of the acceptance test for an in-range k
-EPI_HD double btrs_ub(const BtrsConsts& C, double kd)
+// floor of the defining candidate expression, limited to +-2^30 (far outside [0, n] - floor(c) either way)
+EPI_HD_OUTLINE int32_t btrs_kfloor_exact(float a2, float b, float cfr, float u, float us)
+{
+    double x = __builtin_floor(((double)a2 / (double)us + (double)b) * (double)u + (double)cfr);
+    x = x < -1073741824.0 ? -1073741824.0 : x;
+    x = x > 1073741824.0 ? 1073741824.0 : x;
+    return (int32_t)x;
+}
+
+// left side of the acceptance test
+EPI_HD_OUTLINE double btrs_lv(float v, float us, float a2, float b, float spq)
+{
+    if (!(v > 0.0f)) return -__builtin_inf();
+    const double alpha = (2.83 + 5.1 / (double)b) * (double)spq;
+    return s_log((double)v * alpha / (0.5 * (double)a2 / ((double)us * (double)us) + (double)b));
+}
+
+// right side for a k in [0, n]
+EPI_HD double btrs_ub(const BtrsConsts& C, int32_t k, double lpq, const LfTable& lf)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (C.nd < (double)C.lf.n) {            // every argument is inside the table: four loads, no branches
-        const double* __restrict__ t = C.lf.t;
-        const int32_t ni = (int32_t)C.nd, mi = (int32_t)C.m, ki = (int32_t)kd;
-        return ((t[mi] + t[ni - mi]) - (t[ki] + t[ni - ki])) + (kd - C.m) * C.lpq;
+    if (C.n < lf.n) {                        // every argument is inside the table: four loads, no branches
+        const double* __restrict__ t = lf.t;
+        return ((t[C.m] + t[C.n - C.m]) - (t[k] + t[C.n - k])) + (double)(k - C.m) * lpq;
     }
 #endif
-    return ((lfact_of(C.lf, C.m) + lfact_of(C.lf, C.nd - C.m)) - (lfact_of(C.lf, kd) + lfact_of(C.lf, C.nd - kd))) + (kd - C.m) * C.lpq;
+    return ((lfact_of(lf, (double)C.m) + lfact_of(lf, (double)(C.n - C.m))) - (lfact_of(lf, (double)k) + lfact_of(lf, (double)(C.n - k)))) + (double)(k - C.m) * lpq;
 }
 
-// k = floor((2a/us + b) u + c) of one attempt
-EPI_HD double btrs_k(const BtrsConsts& C, double u, double us)
-{
-    double kd = 0.0;
-    bool have_k = false;
 #ifdef EPI_HAVE_SCREEN
-    if (C.scr) {
-        // k = floor((2a/us + b) u + c) estimated in binary32; trusted when the value is
-        // further from an integer than many times its error bound
-        const float t = __builtin_fmaf(__builtin_fmaf(2.0f * C.af, f_rcp((float)us), C.bf), (float)u, C.cfr);
-        const float tf = __builtin_floorf(t);
-        const float fr = t - tf;
-        const float dl = __builtin_fmaf(__builtin_fabsf(t) + C.bf, 4e-6f, 1e-3f);
-        if (fr > dl && fr < 1.0f - dl) { kd = C.cfl + (double)tf; have_k = true; }
-    }
-#endif
-    if (!have_k) kd = __builtin_floor((2.0 * C.a / us + C.b) * u + C.c);
-    return kd;
+// Binary32 estimates (device only).  The candidate's floor is trusted when the binary32 value of the expression is
+// further from an integer than its error bound: the hardware reciprocal is good to one ulp and two fused
+// multiply-adds follow, so |estimate - exact| < 2.4e-7 (|x| + b); the band is four times that.
+__device__ __forceinline__ bool btrs_kfloor_screen(const BtrsConsts& C, float u, float us, float& r_us, int32_t& kf)
+{
+    r_us = f_rcp(us);
+    const float x = __builtin_fmaf(__builtin_fmaf(C.a2, r_us, C.b), u, C.cfr);
+    const float fl = __builtin_floorf(x);
+    const float fr = x - fl;
+    const float dl = __builtin_fmaf(__builtin_fabsf(x) + C.b, 1e-6f, 1e-6f);
+    kf = (int32_t)__builtin_amdgcn_fmed3f(fl, -1073741824.0f, 1073741824.0f);
+    return fr > dl && fr < 1.0f - dl;
 }
-
-// one attempt: returns the accepted k (>= 0) or -1
-EPI_HD int32_t btrs_attempt(const BtrsConsts& C, uint32_t wa, uint32_t wb)
+// Estimate of btrs_lv: argument good to 8 roundings and two hardware reciprocals (1e-6), the hardware log2 to one ulp
+// of its result, so |estimate - exact| < 1e-6 + 3e-7 |lv|; the band is ten times that.
+constexpr float BTRS_GUARD_REL = 3e-6f, BTRS_GUARD_ABS = 1e-5f;
+__device__ __forceinline__ float btrs_lv_screen(const BtrsConsts& C, float v, float r_us)
 {
-    const double u = u01_centred(wa);
-    const double v = u01(wb);
-    const double us = 0.5 - __builtin_fabs(u);
-    const double kd = btrs_k(C, u, us);
-    if (kd < 0.0 || kd > C.nd) return -1;
-    if (us >= 0.07 && v <= C.vr) return (int32_t)kd;
-#if defined(EPI_HAVE_SCREEN)
-    // the table loads of the right side are issued first and the binary32 estimate of the left side, which does not
-    // depend on them, is computed while they are in flight
-    if (C.nd < (double)C.lf.n) {
-        const double* __restrict__ t = C.lf.t;
-        const int32_t ni = (int32_t)C.nd, mi = (int32_t)C.m, ki = (int32_t)kd;
-        const double t0 = t[mi], t1 = t[ni - mi], t2 = t[ki], t3 = t[ni - ki];
-        const float lvf = btrs_lv_screen(C, us, v);
-        // with the screens switched off the band is infinite: every attempt takes the defining expression
-        const double guard = C.scr ? (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS) : __builtin_inf();
-        const double lvd = (double)lvf, lin = (kd - C.m) * C.lpq;
-        const double ub = ((t0 + t1) - (t2 + t3)) + lin;
-        const double diff = lvd - ub;
-        if (diff < -guard) return (int32_t)kd;
-        if (diff > guard) return -1;
-        return btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? (int32_t)kd : -1;
-    }
+    const float den = C.b * __builtin_fmaf(0.5f * C.a2, r_us * r_us, C.b);          // b (a / us^2 + b)
+    const float num = (v * C.spq) * __builtin_fmaf(2.83f, C.b, 5.1f);               // v alpha b
+    return f_ln(num * f_rcp(den));
+}
 #endif
-    const double ub = btrs_ub(C, kd);
+
+// One attempt: the accepted k (>= 0) or -1.  screen: the device may decide by its binary32 estimates.
+EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, bool screen, uint32_t wa, uint32_t wb)
+{
+    const float u = btrs_u(wa), us = btrs_us(u), v = btrs_v(wb);
+    int32_t kf;
 #ifdef EPI_HAVE_SCREEN
-    if (C.scr) {
-        const float lvf = btrs_lv_screen(C, us, v);
+    float r_us;
+    const bool sure = btrs_kfloor_screen(C, u, us, r_us, kf);
+    if (!(screen && sure)) kf = btrs_kfloor_exact(C.a2, C.b, C.cfr, u, us);
+#else
+    (void)screen;
+    kf = btrs_kfloor_exact(C.a2, C.b, C.cfr, u, us);
+#endif
+    const int32_t k = C.ci + kf;
+    if ((uint32_t)k > (uint32_t)C.n) return -1;
+    if (us >= 0.07f && (0.92f - v) * C.b >= 4.2f) return k;
+    const double ub = btrs_ub(C, k, lpq, lf);
+#ifdef EPI_HAVE_SCREEN
+    if (screen) {
+        const float lvf = btrs_lv_screen(C, v, r_us);
         const double diff = (double)lvf - ub;
         const double guard = (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS);
-        if (diff < -guard) return (int32_t)kd;
+        if (diff < -guard) return k;
         if (diff > guard) return -1;
     }
 #endif
-    return btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? (int32_t)kd : -1;
+    return btrs_lv(v, us, C.a2, C.b, C.spq) <= ub ? k : -1;
 }
 
 #if defined(EPI_HAVE_SCREEN)
-// The constants and one attempt in the order that suits the device.  When every argument of the acceptance test lies
-// inside the log-factorial table, every lane runs one straight sequence: a wave executes the acceptance test of nearly
-// every draw anyway (some lane is outside the squeeze region), and without the branches the four table loads can be
-// issued as soon as k is known; the second part of the constants, the squeeze test and the binary32 estimate of the
-// left side are computed while the loads are in flight.  Same operations on the same values as btrs_consts +
-// btrs_attempt, hence the same result; C is complete on return (for btrs_finish).
-__device__ __forceinline__ int32_t btrs_try(BtrsConsts& C, int32_t n, double pp, double lpq, const LfTable& lf, bool screen,
-                                            uint32_t wa, uint32_t wb)
+// The part of an attempt that needs no table and no logarithm: true = accepted inside the squeeze region with a
+// candidate whose floor the binary32 estimate settles (k valid).  false = everything else: btrs_attempt on the same
+// words gives the outcome.
+__device__ __forceinline__ bool btrs_fast(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k)
 {
-    btrs_consts_k(C, n, pp, lpq, lf, screen);
-    if (C.nd < (double)lf.n) {
-        const double u = u01_centred(wa);
-        const double us = 0.5 - __builtin_fabs(u);
-        const double kd = btrs_k(C, u, us);
-        const bool inr = !(kd < 0.0 || kd > C.nd);
-        // global address space and unsigned 32-bit indices: base in scalar registers + 32-bit offset, no 64-bit address arithmetic
-        typedef const char __attribute__((address_space(1)))* GlobalBytes;
-        typedef const double __attribute__((address_space(1)))* GlobalDoubles;
-        const GlobalBytes t = (GlobalBytes)lf.t;
-        const uint32_t ni = (uint32_t)n, mi = (uint32_t)(int32_t)C.m;
-        const int32_t ki = inr ? (int32_t)kd : 0;                                   // an out-of-range k is rejected below
-        // (the table holds 2^20 doubles: byte offsets fit 32 bits)
-        const double t0 = *(GlobalDoubles)(t + (mi << 3)), t1 = *(GlobalDoubles)(t + ((ni - mi) << 3));
-        const double t2 = *(GlobalDoubles)(t + ((uint32_t)ki << 3)), t3 = *(GlobalDoubles)(t + ((ni - (uint32_t)ki) << 3));
-        __builtin_amdgcn_sched_barrier(0);                                          // nothing below moves above the loads
-        btrs_consts_rest(C);
-        const double v = u01(wb);
-        const bool squeeze = us >= 0.07 && v <= C.vr;
-        const float lvf = btrs_lv_screen(C, us, v);
-        // with the screens switched off the band is infinite (or NaN, which no comparison passes): every attempt outside the
-        // squeeze takes the defining expression.  `screen` is wave-uniform, so the two constants are chosen by scalar selects.
-        const float grel = screen ? BTRS_GUARD_REL : __builtin_inff(), gabs = screen ? BTRS_GUARD_ABS : __builtin_inff();
-        const double guard = (double)__builtin_fmaf(__builtin_fabsf(lvf), grel, gabs);
-        const double lvd = (double)lvf, lin = (kd - C.m) * C.lpq;
-        const double ub = ((t0 + t1) - (t2 + t3)) + lin;
-        const double diff = lvd - ub;
-        const bool acc = squeeze || diff < -guard;
-        int32_t res = (inr && acc) ? ki : -1;
-        if (inr && !acc && !(diff > guard)) res = btrs_lv(v, us, C.a, C.b, C.alpha) <= ub ? ki : -1;
-        return res;
-    }
-    btrs_consts_rest(C);
-    return btrs_attempt(C, wa, wb);
+    const float u = btrs_u(wa), us = btrs_us(u), v = btrs_v(wb);
+    float r_us; int32_t kf;
+    const bool sure = btrs_kfloor_screen(C, u, us, r_us, kf);
+    k = C.ci + kf;
+    return sure && (uint32_t)k <= (uint32_t)C.n && us >= 0.07f && (0.92f - v) * C.b >= 4.2f;
 }
 #else
-// (the host pass over the kernel bodies, and a host restatement, see the plain composition)
-EPI_HD int32_t btrs_try(BtrsConsts& C, int32_t n, double pp, double lpq, const LfTable& lf, bool screen, uint32_t wa, uint32_t wb)
-{
-    C = btrs_consts(n, pp, lpq, lf, screen);
-    return btrs_attempt(C, wa, wb);
-}
+// (the host pass over the kernel bodies sees a declaration; only device code calls it)
+__device__ bool btrs_fast(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k);
 #endif
 
 // Word pair of attempt `att` (>= 1) of a retry stream: block (att-1)/2, words (0,1) or (2,3).
@@ -569,7 +528,7 @@ EPI_HD void retry_pair(const Rng& g, uint32_t retry_kind, uint32_t bin, uint32_t
 }
 
 // remaining attempts of a rejection draw, from attempt `att` (>= 1) on
-EPI_HD int32_t btrs_finish(const BtrsConsts& C, const Rng& g, uint32_t kind, uint32_t bin, uint32_t att)
+EPI_HD int32_t btrs_finish(const BtrsConsts& C, double lpq, const LfTable& lf, bool screen, const Rng& g, uint32_t kind, uint32_t bin, uint32_t att)
 {
     uint32_t w[4] = {0u, 0u, 0u, 0u};
     bool have = false;
@@ -577,10 +536,10 @@ EPI_HD int32_t btrs_finish(const BtrsConsts& C, const Rng& g, uint32_t kind, uin
     for (; att < BINOM_MAX_ATTEMPTS; att++) {
         const bool half = ((att - 1u) & 1u) != 0u;
         if (!have || !half) { rng_block(g, kind, bin, (att - 1u) >> 1, w); have = true; }
-        const int32_t k = btrs_attempt(C, half ? w[2] : w[0], half ? w[3] : w[1]);
+        const int32_t k = btrs_attempt(C, lpq, lf, screen, half ? w[2] : w[0], half ? w[3] : w[1]);
         if (k >= 0) return k;
     }
-    return (int32_t)C.m;                     // only if every attempt fails
+    return C.m;                              // only if every attempt fails
 }
 
 // fa, fb: the attempt-0 word pair; attempts a >= 1 come from blocks of retry_kind.
@@ -593,11 +552,98 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
     if (cls == BINOM_DONE) return x;
     if (cls == BINOM_INVERSION) x = binom_inversion(n, s_log(1.0 - pp), pp / (1.0 - pp), fa);
     else {
-        const BtrsConsts C = btrs_consts(n, pp, s_log(pp / (1.0 - pp)), lf, screen);
-        x = btrs_attempt(C, fa, fb);
-        if (x < 0) x = btrs_finish(C, g, retry_kind, bin, 1u);
+        const BtrsBin B = btrs_bin(pp);
+        const BtrsConsts C = btrs_consts(n, B);
+        x = btrs_attempt(C, B.lpq, lf, screen, fa, fb);
+        if (x < 0) x = btrs_finish(C, B.lpq, lf, screen, g, retry_kind, bin, 1u);
     }
     return flip ? n - x : x;
+}
+
+// ---- standard normal: ziggurat (Marsaglia & Tsang 2000), 128 strips of equal area ----------------------------
+// Strip k = 1..127 is the rectangle [0, x_k] x [f(x_k), f(x_{k+1})], f(x) = exp(-x^2 / 2), x_1 = r > x_2 > ... >
+// x_128 = 0; strip 0 is [0, r] x [0, f(r)] plus the tail beyond r, with nominal width X_0 = area / f(r).  One 32-bit
+// word gives the strip (bits 0-6), the sign (bit 7) and a 24-bit position j: x = fl(j) wn[k], wn[k] = X_k 2^-24.
+// j < kn[k] (x inside the part of the strip that lies wholly under the curve): x is returned.  That is all the
+// fast path does: one 8-byte table entry, a conversion, a multiplication and a comparison, for 98.8 % of the words.
+// Otherwise (zig_slow): a wedge point is accepted iff f(x_k) + U (f(x_{k+1}) - f(x_k)) < f(x); the tail is
+// Marsaglia's: x = -log(U1) / r, accepted iff -2 log(U2) > x^2, giving r + x; a rejected wedge point starts over
+// with a fresh word, a rejected tail point repeats the tail step.  Step l of this takes Philox block l of the
+// stream (K_ZIG, attempt << 6 | term): words 0, 1 -> U, U1 / U2 (32-bit binary64 uniforms), word 2 -> the next
+// candidate word.  The slow path is binary64 throughout (s_exp, s_log as above).
+constexpr int ZIG_N = 128;
+constexpr uint32_t K_ZIG = 8u;
+constexpr uint32_t ZIG_MAX_STEPS = 64u;
+struct ZigEntry { uint32_t kn; float wn; };
+struct ZigTable {
+    ZigEntry e[ZIG_N];
+    double fn[ZIG_N + 1];        // f(x_k), k = 1..128 (fn[0] unused)
+    double r;
+};
+
+// (host) the table, from the strip area and r of the published 128-strip construction
+inline void zig_build(ZigTable& T)
+{
+    const double r = 3.442619855899, v = 9.91256303526217e-3;
+    double x[ZIG_N + 1];
+    x[1] = r;
+    for (int k = 1; k < ZIG_N - 1; k++) x[k + 1] = __builtin_sqrt(-2.0 * s_log(v / x[k] + s_exp(-0.5 * x[k] * x[k])));
+    x[ZIG_N] = 0.0;
+    T.r = r;
+    T.fn[0] = 0.0;
+    for (int k = 1; k <= ZIG_N; k++) T.fn[k] = k == ZIG_N ? 1.0 : s_exp(-0.5 * x[k] * x[k]);
+    for (int k = 0; k < ZIG_N; k++) {
+        const double X = k == 0 ? v / T.fn[1] : x[k];
+        const double inner = x[k + 1];                       // k = 0: r
+        T.e[k].wn = (float)(X * 0x1p-24);
+        // every position below kn lies under the curve whatever the rounding of wn and of the product
+        T.e[k].kn = (uint32_t)((inner / (double)T.e[k].wn) * (1.0 - 0x1p-22));
+    }
+}
+
+EPI_HD bool zig_fast(uint32_t w, const ZigEntry e, float& x)
+{
+    const uint32_t j = w >> 8;
+    const float xa = (float)j * e.wn;
+    x = u2f(f2u(xa) | ((w & 128u) << 24));
+    return j < e.kn;
+}
+
+// everything else; term_att = attempt << 6 | infection term
+EPI_HD_OUTLINE float zig_slow(const ZigTable* __restrict__ T, const Rng g, uint32_t term_att, uint32_t w)
+{
+    bool tail = false;
+    uint32_t sign = 0u;
+    float x = 0.f;
+#pragma unroll 1
+    for (uint32_t l = 0; l < ZIG_MAX_STEPS; l++) {
+        uint32_t q[4];
+        rng_block(g, K_ZIG, term_att, l, q);
+        if (!tail) {
+            const uint32_t k = w & 127u, j = w >> 8;
+            sign = (w & 128u) << 24;
+            x = (float)j * T->e[k].wn;
+            if (j < T->e[k].kn) break;
+            if (k == 0u) tail = true;
+            else {
+                const double xd = (double)x;
+                const double y = T->fn[k] + u01(q[0]) * (T->fn[k + 1] - T->fn[k]);
+                if (y < s_exp(-0.5 * xd * xd)) break;
+                w = q[2];
+                continue;
+            }
+        }
+        const double xt = -s_log(u01(q[0])) / T->r, yt = -s_log(u01(q[1]));
+        if (yt + yt > xt * xt) { x = (float)(T->r + xt); break; }
+    }
+    return u2f(f2u(x) | sign);
+}
+
+EPI_HD float zig_normal(const ZigTable* __restrict__ T, const Rng& g, uint32_t term_att, uint32_t w)
+{
+    float x;
+    if (zig_fast(w, T->e[w & 127u], x)) return x;
+    return zig_slow(T, g, term_att, w);
 }
 
 // ---- Gamma(shape, scale) --------------------------------------------------------
@@ -608,27 +654,27 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
 constexpr uint32_t GAMMA_MAX_ATTEMPTS = 512u;
 
 struct GammaConsts {
-    double shape, d, c;
+    double shape, d;
+    float c;
     bool boost, screen;
 };
 
 EPI_HD bool gamma_is_zero(double shape) { return !(shape >= 0x1p-30); }
 
-// c >= 1 / sqrt(9 d), and within 3e-10 of it.  Marsaglia-Tsang's rejection is exact for every such c: with
-// v = (1 + c x)^3, h(x) = d (log v - v + 1) <= -(9 d c^2) x^2 / 2 <= -x^2 / 2, so the normal envelope dominates, and
-// d v has the Gamma(d + 1/3) density whatever c is.  c = 1 / sqrt(9 d) only maximises the acceptance rate, so three
-// Newton steps for the reciprocal square root (plain multiplies and subtractions, from the bit-shift seed; the
-// iterates approach the root from below) and a final factor 1 + 2^-32 replace the square root and the division.
-// The squeeze u < 1 - 0.0331 x^4 then overstates the acceptance probability by at most 2.4e-10 x^2, the
-// granularity of the 32-bit uniform u itself.
-EPI_HD double gamma_c(double d)
+// c >= 1 / sqrt(9 d) with 1 <= 9 d c^2 <= 1 + 1.4e-5, in binary32: two Newton steps for the reciprocal square root
+// from the bit-shift seed (relative error 3.4e-2 -> 1.8e-3 -> 4.8e-6, the iterates below the root) and a factor
+// 1 + 6e-6.  Marsaglia-Tsang's rejection is exact for every c >= 1 / sqrt(9 d): with v = (1 + c x)^3,
+// h(x) = d (log v - v + 1) <= -(9 d c^2) x^2 / 2 <= -x^2 / 2, so the normal envelope dominates, and d v has the
+// Gamma(d + 1/3) density whatever c is; c = 1 / sqrt(9 d) only maximises the acceptance rate.  The squeeze has to
+// allow for the excess: with 9 d c^2 = 1 + 2 e the acceptance probability is exp(-e x^2) times the one at
+// x' = x sqrt(1 + 2 e), which is at least 1 - 0.0331 x'^4, hence >= 1 - 0.03311 x^4 - 1.4e-5 x^2.
+EPI_HD float gamma_c(float d)
 {
-    const double h = 4.5 * d;                                  // (9 d) / 2
-    double y = u2d(0x5FE6EB50C7B537A9ULL - (d2u(9.0 * d) >> 1));
-    y = y * (1.5 - h * (y * y));
-    y = y * (1.5 - h * (y * y));
-    y = y * (1.5 - h * (y * y));
-    return y * 1.00000000023283064365386962890625;             // 1 + 2^-32
+    const float x9 = 9.0f * d, h = 4.5f * d;
+    float y = u2f(0x5f3759dfu - (f2u(x9) >> 1));
+    y = y * (1.5f - h * (y * y));
+    y = y * (1.5f - h * (y * y));
+    return y * 1.000006f;
 }
 
 EPI_HD GammaConsts gamma_consts(double shape, bool screen)
@@ -638,16 +684,29 @@ EPI_HD GammaConsts gamma_consts(double shape, bool screen)
     G.boost = shape < 1.0;
     const double al = G.boost ? shape + 1.0 : shape;
     G.d = al - 0.3333333333333333;
-    G.c = gamma_c(G.d);
+    G.c = gamma_c((float)G.d);
     G.screen = screen;
     return G;
 }
 
+EPI_HD float gamma_u(uint32_t wu) { return (float)wu * 0x1p-32f; }
+
+// The squeeze: true = accepted without a logarithm (v valid).  t = 1 + c x <= 0 is never accepted.
+EPI_HD bool gamma_fast(const GammaConsts& G, float xf, uint32_t wu, double& v)
+{
+    const double t = __builtin_fma((double)G.c, (double)xf, 1.0);
+    v = t * t * t;
+    const float x2 = xf * xf;
+    const float sq = __builtin_fmaf(-0.03311f, x2 * x2, __builtin_fmaf(-1.4e-5f, x2, 0.9999998f));
+    return t > 0.0 && gamma_u(wu) < sq;
+}
+
 #ifdef EPI_HAVE_SCREEN
 // binary32 estimate of log u - [x^2/2 + d (1 - v + log v)] (accept iff < 0) for t = c x > -0.9, and the sum
-// `mag` of the magnitudes of its terms; estimate error < 1.5e-6 mag + 1e-6 by the same rounding analysis
-// (measured over 2e8 undecided attempts, shapes 1 to 1e8: never above 2e-7 mag + 5e-6).
-constexpr float GAMMA_GUARD_REL = 5e-6f, GAMMA_GUARD_ABS = 1e-4f;
+// `mag` of the magnitudes of its terms.  The estimate takes 9 d c^2 = 1, i.e. x^2 / 2 = 4.5 d t^2, which the
+// constants above satisfy to 1.4e-5 (an error below 7e-6 x^2, covered by the x^2 term of the band); otherwise the
+// error is below 1.5e-6 mag + 1e-6 by rounding analysis.
+constexpr float GAMMA_GUARD_REL = 5e-6f, GAMMA_GUARD_ABS = 1e-4f, GAMMA_GUARD_X2 = 2e-5f;
 __device__ __forceinline__ float gamma_screen(float tf, float df, float uf, float& mag)
 {
     const float t2 = tf * tf;
@@ -672,28 +731,29 @@ __device__ __forceinline__ float gamma_screen(float tf, float df, float uf, floa
 
 EPI_HD bool gamma_attempt(const GammaConsts& G, float xf, uint32_t wu, double& v)
 {
-    const double x = (double)xf;
-    const double u = u01(wu);
-    const double t = 1.0 + G.c * x;
-    if (!(t > 0.0)) return false;
-    const double vv = t * t * t;
-    const double x2 = x * x;
+    double vv;
+    const bool fast = gamma_fast(G, xf, wu, vv);
     v = vv;
-    if (u < 1.0 - 0.0331 * (x2 * x2)) return true;
+    if (fast) return true;
+    const double x = (double)xf;
+    const double t = __builtin_fma((double)G.c, x, 1.0);
+    if (!(t > 0.0)) return false;
+    const float uf = gamma_u(wu);
+    if (!(uf > 0.0f)) return true;
+    const double x2 = x * x;
 #ifdef EPI_HAVE_SCREEN
     if (G.screen) {
-        // x^2/2 + d (1 - v + log v) = 3 d (log1p(t) - t + t^2/2 - t^3/3), t = c x  (since 9 d c^2 = 1)
-        const float tf = (float)G.c * xf;
+        const float tf = G.c * xf;
         if (tf > -0.9f) {
             float mag;
-            const float diff = gamma_screen(tf, (float)G.d, (float)u, mag);
-            const float guard = __builtin_fmaf(mag, GAMMA_GUARD_REL, GAMMA_GUARD_ABS);
+            const float diff = gamma_screen(tf, (float)G.d, uf, mag);
+            const float guard = __builtin_fmaf(xf * xf, GAMMA_GUARD_X2, __builtin_fmaf(mag, GAMMA_GUARD_REL, GAMMA_GUARD_ABS));
             if (diff < -guard) return true;
             if (diff > guard) return false;
         }
     }
 #endif
-    return s_log(u) < 0.5 * x2 + G.d * (1.0 - vv + s_log(vv));
+    return s_log((double)uf) < 0.5 * x2 + G.d * (1.0 - vv + s_log(vv));
 }
 
 // U^(1/shape) of the boost for shape < 1 (out of line on the device, for the same reason as binom_inversion)
@@ -712,53 +772,49 @@ EPI_HD double gamma_finish(const GammaConsts& G, double v, double scale, const R
     return gval * scale;
 }
 
-// attempt-0 normal and word of infection term `bin` (shared block of the pair bin/2)
-EPI_HD void gamma_first(const Rng& g, uint32_t bin, float& zf, uint32_t& wu)
+// words of attempt 0 of infection term `bin` (shared block of the pair bin/2): candidate word of the normal, word of the uniform
+EPI_HD void gamma_first(const Rng& g, uint32_t bin, uint32_t& wz, uint32_t& wu)
 {
     uint32_t w[4];
-    float z0, z1;
     rng_block(g, K_GAMMA, bin >> 1, 0, w);
-    box_muller(w[0], w[1], z0, z1);
-    zf = (bin & 1u) ? z1 : z0;
+    wz = (bin & 1u) ? w[1] : w[0];
     wu = (bin & 1u) ? w[3] : w[2];
 }
 
-// normal and word of attempt att >= 1
-EPI_HD void gamma_retry(const Rng& g, uint32_t bin, uint32_t att, float& zf, uint32_t& wu)
+// words of attempt att >= 1
+EPI_HD void gamma_retry(const Rng& g, uint32_t bin, uint32_t att, uint32_t& wz, uint32_t& wu)
 {
     uint32_t w[4];
-    float z0, z1;
     rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w);
-    box_muller(w[0], w[1], z0, z1);
     const bool half = ((att - 1u) & 1u) != 0u;
-    zf = half ? z1 : z0;
+    wz = half ? w[1] : w[0];
     wu = half ? w[3] : w[2];
 }
 
 // remaining attempts of a gamma draw from attempt `att` (>= 1) on, then boost and scale
-EPI_HD double gamma_finish_from(const GammaConsts& G, double scale, const Rng& g, uint32_t bin, uint32_t att)
+EPI_HD double gamma_finish_from(const GammaConsts& G, double scale, const ZigTable* __restrict__ Z, const Rng& g, uint32_t bin, uint32_t att)
 {
     double v = 1.0, vv;                        // v = 1 only if every attempt fails
     uint32_t w[4] = {0u, 0u, 0u, 0u};
-    float z0 = 0.f, z1 = 0.f;
     bool have = false;
 #pragma unroll 1
     for (; att < GAMMA_MAX_ATTEMPTS; att++) {
         const bool half = ((att - 1u) & 1u) != 0u;
-        if (!have || !half) { rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w); box_muller(w[0], w[1], z0, z1); have = true; }
-        if (gamma_attempt(G, half ? z1 : z0, half ? w[3] : w[2], vv)) { v = vv; break; }
+        if (!have || !half) { rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w); have = true; }
+        const float xf = zig_normal(Z, g, (att << 6) | bin, half ? w[1] : w[0]);
+        if (gamma_attempt(G, xf, half ? w[3] : w[2], vv)) { v = vv; break; }
     }
     return gamma_finish(G, v, scale, g, bin);
 }
 
-// zf, wu: the attempt-0 normal and word (gamma_first)
-EPI_HD double gamma_draw(double shape, double scale, float zf, uint32_t wu, const Rng& g, uint32_t bin, bool screen = true)
+// wz, wu: the attempt-0 words (gamma_first)
+EPI_HD double gamma_draw(double shape, double scale, uint32_t wz, uint32_t wu, const ZigTable* __restrict__ Z, const Rng& g, uint32_t bin, bool screen = true)
 {
     if (gamma_is_zero(shape)) return 0.0;
     const GammaConsts G = gamma_consts(shape, screen);
     double vv;
-    if (gamma_attempt(G, zf, wu, vv)) return gamma_finish(G, vv, scale, g, bin);
-    return gamma_finish_from(G, scale, g, bin, 1u);
+    if (gamma_attempt(G, zig_normal(Z, g, bin, wz), wu, vv)) return gamma_finish(G, vv, scale, g, bin);
+    return gamma_finish_from(G, scale, Z, g, bin, 1u);
 }
 
 // 53-bit uniform in [0,1) of the systematic resampler for (seed, step)

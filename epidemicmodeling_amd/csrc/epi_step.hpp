@@ -39,11 +39,15 @@ __host__ __device__ __forceinline__ int tests_row(int H, int r0, int c0) { retur
 // Everything one binomial draw of one age bin reads from the parameters, in one 64-byte record: the kernels fetch it
 // with a single wide scalar load (one wait) instead of a chain of dependent loads from the separate tables below.
 struct alignas(64) BinConsts {
-    double pp, lpq, lnq, sr;    // as in the tables below
+    double lpq, lnq, sr;        // as in the tables below
     const double* lf_t;         // the log-factorial table (same for every bin)
+    uint32_t ppx;               // the rejection sampler's per-probability constants (btrs_bin)
+    float pq, a0x2;
     uint32_t nthr;
     int32_t kind, flip, lf_n;
+    __host__ __device__ __forceinline__ BtrsBin btrs() const { return BtrsBin{ppx, pq, a0x2, lpq}; }
 };
+static_assert(sizeof(BinConsts) == 64, "one 64-byte record per (draw, bin)");
 
 struct DevParams {
     epi_params P;
@@ -59,6 +63,7 @@ struct DevParams {
     int32_t flip[2][EPI_MAX_H]; // p > 1/2: the draw is n - Binomial(n, 1 - p)
     LfTable lf;                 // tabulated log factorials (device memory; null on the host)
     BinConsts bc[2][EPI_MAX_H]; // the same constants per (draw, bin); filled by pack_bin_consts once lf is set
+    ZigTable zig;               // strips of the normal generator
 };
 
 inline void pack_bin_consts(DevParams& D)
@@ -66,7 +71,9 @@ inline void pack_bin_consts(DevParams& D)
     for (int j = 0; j < 2; j++)
         for (int i = 0; i < EPI_MAX_H; i++) {
             BinConsts& b = D.bc[j][i];
-            b.pp = D.pp[j][i]; b.lpq = D.lpq[j][i]; b.lnq = D.lnq[j][i]; b.sr = D.sr[j][i];
+            const BtrsBin B = btrs_bin(D.pp[j][i]);
+            b.lpq = B.lpq; b.lnq = D.lnq[j][i]; b.sr = D.sr[j][i];
+            b.ppx = B.ppx; b.pq = B.pq; b.a0x2 = B.a0x2;
             b.lf_t = D.lf.t; b.lf_n = D.lf.n;
             b.nthr = D.nthr[j][i]; b.kind = D.kind[j][i]; b.flip = D.flip[j][i];
         }
@@ -126,9 +133,10 @@ __device__ __forceinline__ int32_t bin_binomial(const DevParams& D, int bin, int
     const bool flip = D.flip[j][bin] != 0;
     if (cls == BINOM_INVERSION) x = binom_inversion(n, D.lnq[j][bin], D.sr[j][bin], fa);
     else {
-        const BtrsConsts C = btrs_consts(n, D.pp[j][bin], D.lpq[j][bin], D.lf, screen);
-        x = btrs_attempt(C, fa, fb);
-        if (x < 0) x = btrs_finish(C, g, j ? K_POS : K_SYMPT, (uint32_t)bin, 1u);
+        const BtrsBin B = D.bc[j][bin].btrs();
+        const BtrsConsts C = btrs_consts(n, B);
+        x = btrs_attempt(C, B.lpq, D.lf, screen, fa, fb);
+        if (x < 0) x = btrs_finish(C, B.lpq, D.lf, screen, g, j ? K_POS : K_SYMPT, (uint32_t)bin, 1u);
     }
     return flip ? n - x : x;
 }
@@ -138,7 +146,7 @@ struct PhiloxDraws {
     Rng g;
     bool screen;    // allow the binary32 screens of the rejection samplers (results do not depend on it)
     const DevParams* D;
-    mutable float z_odd;        // second normal / word of the last gamma pair block
+    mutable uint32_t z_odd;     // words of the odd term of the last gamma pair block
     mutable uint32_t w_odd;
     __device__ __forceinline__ void binomials(int bin, int32_t n_inf, double, int32_t n_tested, double,
                                                int32_t& sympt, int32_t& pos) const
@@ -155,15 +163,13 @@ struct PhiloxDraws {
     // infection terms are drawn in order 0, 1, 2, ...: an even term generates the block of its pair
     __device__ __forceinline__ double gamma(int bin, double shape, double scale) const
     {
-        float zf; uint32_t wu;
+        uint32_t wz, wu;
         if ((bin & 1) == 0) {
             uint32_t w[4];
-            float z0, z1;
             rng_block(g, K_GAMMA, (uint32_t)bin >> 1, 0, w);
-            box_muller(w[0], w[1], z0, z1);
-            zf = z0; wu = w[2]; z_odd = z1; w_odd = w[3];
-        } else { zf = z_odd; wu = w_odd; }
-        return gamma_draw(shape, scale, zf, wu, g, (uint32_t)bin, screen);
+            wz = w[0]; wu = w[2]; z_odd = w[1]; w_odd = w[3];
+        } else { wz = z_odd; wu = w_odd; }
+        return gamma_draw(shape, scale, wz, wu, &D->zig, g, (uint32_t)bin, screen);
     }
 };
 

@@ -114,8 +114,8 @@ void orc_philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out[4]
 #define K_BINOM0  0u  /* words 0,1: sympt attempt 0 ; words 2,3: pos attempt 0      */
 #define K_SYMPT   1u  /* blk j: sympt attempts 1+2j (words 0,1) and 2+2j (words 2,3) */
 #define K_POS     2u  /* same for pos                                              */
-#define K_GAMMA   3u  /* bin = pair j: attempt 0 of infection term 2j (z0, word 2), of term 2j+1 (z1, word 3) */
-#define K_GRETRY  7u  /* bin = term, blk b: its attempts 1+2b (z0, word 2) and 2+2b (z1, word 3) */
+#define K_GAMMA   3u  /* bin = pair j: attempt 0 of infection term 2j (words 0, 2), of term 2j+1 (words 1, 3) */
+#define K_GRETRY  7u  /* bin = term, blk b: its attempts 1+2b (words 0, 2) and 2+2b (words 1, 3) */
 #define K_BOOST   4u  /* word 0: U for the shape<1 boost                            */
 #define K_RESAMP  5u  /* particle = 0: words 0,1 -> 53-bit systematic offset        */
 #define K_INIT    6u  /* initial-state generators                                  */
@@ -317,30 +317,40 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
             r *= s * ((a1 - xd) * t);
         }
     } else {
-        /* hat parameters: sqrt and 1/b in binary32 (Hoermann's constants carry 3 digits) */
-        double spq = (double)sqrtf((float)(nd * pp * qq));
-        double b = 1.15 + 2.53 * spq;
-        double a = -0.0873 + 0.0248 * b + 0.01 * pp;
-        double c = nd * pp + 0.5;
-        double ib = (double)(1.0f / (float)b);
-        double vr = 0.92 - 4.2 * ib;
-        double alpha = (2.83 + 5.1 * ib) * spq;
+        /* Hat in binary32 (Hoermann's constants carry 3 digits); the centre c = n pp + 1/2 and the mode
+         * m = floor((n + 1) pp) exactly, from pp in 0.32 fixed point; the fraction of c to 23 bits. */
+        uint32_t ppx = (uint32_t)(pp * 4294967296.0 + 0.5);
+        float pqf = (float)(pp * qq);
+        float a0x2 = (float)(2.0 * (-0.0873 + 0.01 * pp));
         double lpq = s_log(pp / qq);
-        double m = floor((nd + 1.0) * pp);
-        x = (int64_t)m;                         /* returned only if every attempt fails */
+        float spq = sqrtf((float)(int32_t)n * pqf);
+        float b = fmaf(2.53f, spq, 1.15f);
+        float a2 = fmaf(0.0496f, b, a0x2);                       /* 2 a */
+        uint64_t prod = (uint64_t)(uint32_t)n * ppx + 0x80000000ULL;
+        int64_t ci = (int64_t)(prod >> 32);
+        float cfr = u2f(0x3f800000u | ((uint32_t)prod >> 9)) - 1.0f;
+        int64_t mi = (int64_t)(((uint64_t)((uint32_t)n + 1u) * ppx) >> 32);
+        double m = (double)mi;
+        x = mi;                                 /* returned only if every attempt fails */
         for (uint32_t att = 0; att < BINOM_MAX_ATTEMPTS; att++) {
             uint32_t wa, wb;
             binom_pair(src, att, &wa, &wb);
-            double u = u01(wa) - 0.5;
-            double v = u01(wb);
-            double us = 0.5 - fabs(u);
-            double kd = floor((2.0 * a / us + b) * u + c);
-            if (kd < 0.0 || kd > nd) continue;
-            if (us >= 0.07 && v <= vr) { x = (int64_t)kd; break; }
+            float u = (float)(int32_t)wa * 0x1p-32f;             /* [-1/2, 1/2] */
+            float us = fmaxf(0.5f - fabsf(u), 0x1p-25f);
+            float v = (float)wb * 0x1p-32f;                      /* [0, 1] */
+            double xf = floor(((double)a2 / (double)us + (double)b) * (double)u + (double)cfr);
+            if (xf < -1073741824.0) xf = -1073741824.0;
+            if (xf > 1073741824.0) xf = 1073741824.0;
+            int64_t k = ci + (int64_t)xf;
+            if (k < 0 || k > n) continue;
+            if (us >= 0.07f && (0.92f - v) * b >= 4.2f) { x = k; break; }
+            if (!(v > 0.0f)) { x = k; break; }
             /* log(v alpha / (a/us^2 + b)) <= log f(k) - log f(m), the pmf ratio from log factorials */
-            double lv = s_log(v * alpha / (a / (us * us) + b));
+            double alpha = (2.83 + 5.1 / (double)b) * (double)spq;
+            double lv = s_log((double)v * alpha / (0.5 * (double)a2 / ((double)us * (double)us) + (double)b));
+            double kd = (double)k;
             double ub = ((lfact(m) + lfact(nd - m)) - (lfact(kd) + lfact(nd - kd))) + (kd - m) * lpq;
-            if (lv <= ub) { x = (int64_t)kd; break; }
+            if (lv <= ub) { x = k; break; }
         }
     }
     return flip ? n - x : x;
@@ -354,22 +364,89 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
 #define GAMMA_MAX_ATTEMPTS 512u
 #define GAMMA_MIN_SHAPE 0x1p-30
 
-/* c >= 1/sqrt(9 d) within 3e-10: three Newton steps for the reciprocal square root from the bit-shift seed   */
-/* (the iterates stay below the root) and a factor 1 + 2^-32.  The rejection is exact for every such c: the     */
-/* normal envelope dominates d (log v - v + 1) as soon as 9 d c^2 >= 1, and d v is Gamma(d + 1/3) whatever c.  */
-static inline double gamma_c(double d)
+/* Standard normal by the ziggurat of Marsaglia & Tsang (2000) with 128 strips of equal area v: strip k >= 1 is
+ * [0, x_k] x [f(x_k), f(x_{k+1})], x_1 = r, x_128 = 0, f(x) = exp(-x^2/2); strip 0 is the base [0, r] x [0, f(r)]
+ * plus the tail, nominal width v / f(r).  A 32-bit word gives strip (bits 0-6), sign (bit 7), position j (24 bits). */
+#define ZIG_N 128
+#define K_ZIG 8u
+#define ZIG_MAX_STEPS 64u
+static uint32_t zig_kn[ZIG_N];
+static float zig_wn[ZIG_N];
+static double zig_fn[ZIG_N + 1];
+static const double zig_r = 3.442619855899, zig_v = 9.91256303526217e-3;
+
+__attribute__((constructor)) static void zig_init(void)
 {
-    const double h = 4.5 * d;
-    double x9 = 9.0 * d, y;
-    uint64_t b;
-    memcpy(&b, &x9, 8);
-    b = 0x5FE6EB50C7B537A9ULL - (b >> 1);
-    memcpy(&y, &b, 8);
-    y = y * (1.5 - h * (y * y));
-    y = y * (1.5 - h * (y * y));
-    y = y * (1.5 - h * (y * y));
-    return y * 1.00000000023283064365386962890625;
+    double x[ZIG_N + 1];
+    x[1] = zig_r;
+    for (int k = 1; k < ZIG_N - 1; k++) x[k + 1] = sqrt(-2.0 * s_log(zig_v / x[k] + s_exp(-0.5 * x[k] * x[k])));
+    x[ZIG_N] = 0.0;
+    zig_fn[0] = 0.0;
+    for (int k = 1; k <= ZIG_N; k++) zig_fn[k] = k == ZIG_N ? 1.0 : s_exp(-0.5 * x[k] * x[k]);
+    for (int k = 0; k < ZIG_N; k++) {
+        double X = k == 0 ? zig_v / zig_fn[1] : x[k];
+        zig_wn[k] = (float)(X * 0x1p-24);
+        zig_kn[k] = (uint32_t)((x[k + 1] / (double)zig_wn[k]) * (1.0 - 0x1p-22));
+    }
 }
+
+void orc_zig_table(uint32_t *kn, float *wn, double *fn)
+{
+    memcpy(kn, zig_kn, sizeof zig_kn); memcpy(wn, zig_wn, sizeof zig_wn); memcpy(fn, zig_fn, sizeof zig_fn);
+}
+
+/* the normal of attempt `att` of infection term `term` from its candidate word w; the wedges and the tail take
+ * further words from the blocks 0, 1, ... of the stream (K_ZIG, att << 6 | term) */
+static float zig_normal(const rng_t *g, uint32_t term, uint32_t att, uint32_t w)
+{
+    int tail = 0;
+    uint32_t sign = 0;
+    float x = 0.f;
+    for (uint32_t l = 0; l < ZIG_MAX_STEPS; l++) {
+        if (!tail) {
+            uint32_t k = w & 127u, j = w >> 8;
+            sign = (w & 128u) << 24;
+            x = (float)j * zig_wn[k];
+            if (j < zig_kn[k]) break;                      /* inside the strip's rectangle under the curve */
+            if (k == 0) tail = 1;
+            else {
+                uint32_t q[4];
+                rng_block(g, K_ZIG, (att << 6) | term, l, q);
+                double xd = (double)x;
+                double y = zig_fn[k] + u01(q[0]) * (zig_fn[k + 1] - zig_fn[k]);
+                if (y < s_exp(-0.5 * xd * xd)) break;
+                w = q[2];
+                continue;
+            }
+        }
+        uint32_t q[4];
+        rng_block(g, K_ZIG, (att << 6) | term, l, q);
+        double xt = -s_log(u01(q[0])) / zig_r, yt = -s_log(u01(q[1]));
+        if (yt + yt > xt * xt) { x = (float)(zig_r + xt); break; }
+    }
+    return u2f(f2u(x) | sign);
+}
+
+float orc_zig_normal(uint64_t seed, uint64_t particle, uint32_t step, uint32_t term, uint32_t att, uint32_t w)
+{
+    rng_t g = rng_make(seed, particle, step);
+    return zig_normal(&g, term, att, w);
+}
+
+/* c >= 1/sqrt(9 d), 1 <= 9 d c^2 <= 1 + 1.4e-5, in binary32: two Newton steps for the reciprocal square root   */
+/* from the bit-shift seed (the iterates stay below the root) and a factor 1 + 6e-6.  The rejection is exact for */
+/* every such c: the normal envelope dominates d (log v - v + 1) as soon as 9 d c^2 >= 1, and d v is             */
+/* Gamma(d + 1/3) whatever c; the squeeze below carries the allowance for the excess.                            */
+static inline float gamma_c(float d)
+{
+    const float x9 = 9.0f * d, h = 4.5f * d;
+    float y = u2f(0x5f3759dfu - (f2u(x9) >> 1));
+    y = y * (1.5f - h * (y * y));
+    y = y * (1.5f - h * (y * y));
+    return y * 1.000006f;
+}
+
+float orc_gamma_c(float d) { return gamma_c(d); }
 
 static double gamma_draw(double shape, double scale, const rng_t *g, uint32_t bin)
 {
@@ -377,25 +454,25 @@ static double gamma_draw(double shape, double scale, const rng_t *g, uint32_t bi
     int boost = shape < 1.0;
     double al = boost ? shape + 1.0 : shape;
     double d = al - 0.3333333333333333;
-    double c = gamma_c(d);
+    float c = gamma_c((float)d);
     double v = 1.0;
     uint32_t w[4];
     for (uint32_t att = 0; att < GAMMA_MAX_ATTEMPTS; att++) {
         /* attempt 0 shares the block of the pair bin/2 (half bin&1); attempt a >= 1 takes half (a-1)&1 of
-         * block (a-1)/2 of the term's own retry stream */
+         * block (a-1)/2 of the term's own retry stream; word `half` -> the normal, word 2 + half -> the uniform */
         uint32_t half = att == 0 ? (bin & 1u) : ((att - 1u) & 1u);
         if (att == 0) rng_block(g, K_GAMMA, bin >> 1, 0, w);
         else rng_block(g, K_GRETRY, bin, (att - 1u) >> 1, w);
-        float z0, z1;
-        box_muller(w[0], w[1], &z0, &z1);
-        double x = (double)(half ? z1 : z0);
-        double u = u01(half ? w[3] : w[2]);
-        double t = 1.0 + c * x;
+        float xf = zig_normal(g, bin, att, w[half]);
+        float uf = (float)w[2 + half] * 0x1p-32f;
+        double x = (double)xf;
+        double t = fma((double)c, x, 1.0);
         if (!(t > 0.0)) continue;
         double vv = t * t * t;
-        double x2 = x * x;
-        if (u < 1.0 - 0.0331 * (x2 * x2)) { v = vv; break; }
-        if (s_log(u) < 0.5 * x2 + d * (1.0 - vv + s_log(vv))) { v = vv; break; }
+        float x2f = xf * xf;
+        if (uf < fmaf(-0.03311f, x2f * x2f, fmaf(-1.4e-5f, x2f, 0.9999998f))) { v = vv; break; }
+        if (!(uf > 0.0f)) { v = vv; break; }
+        if (s_log((double)uf) < 0.5 * (x * x) + d * (1.0 - vv + s_log(vv))) { v = vv; break; }
     }
     double gval = d * v;
     if (boost) {

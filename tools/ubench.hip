@@ -72,12 +72,15 @@ __global__ __launch_bounds__(256) void k_div(const double* x, double* out, int64
 // issue rate of single instructions: 8 independent dependency chains per lane, OPS_REP rounds
 constexpr int OPS_REP = 256;
 enum { OP_FMA64, OP_FMA32, OP_PKFMA32, OP_MAD64, OP_MULLO, OP_MULHI, OP_XOR, OP_RCP32, OP_SQRT32, OP_LOG32, OP_RCP64, OP_CVT_F64_U32,
-       OP_CVT_F32_F64, OP_FLOOR64, OP_MUL64, OP_ADD64, OP_LDEXP64, OP_CNDMASK, OP_BITOP3, OP_XOR2 };
+       OP_CVT_F32_F64, OP_FLOOR64, OP_MUL64, OP_ADD64, OP_LDEXP64, OP_CNDMASK, OP_BITOP3, OP_XOR2, OP_PKMUL32, OP_PKADD32, OP_MUL32, OP_ADD32, OP_CVT_F32_I32, OP_CVT_I32_F32, OP_FLOOR32, OP_FRACT32, OP_CMPSEL32, OP_MED3, OP_LDS_RAND, OP_SQRT32_RN, OP_DIV32_RN, OP_MAD_U32_U24, OP_ADD3 };
 template <int OP>
 __global__ __launch_bounds__(256) void k_ops(const double* x, double* out, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    __shared__ uint32_t lds[256];
+    lds[threadIdx.x] = threadIdx.x * 2654435761u;
+    __syncthreads();
     double d[8]; float f[8]; uint32_t u[8]; uint64_t q[8];
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p[8];
@@ -105,6 +108,21 @@ __global__ __launch_bounds__(256) void k_ops(const double* x, double* out, int64
             else if constexpr (OP == OP_LDEXP64) d[c] = __builtin_ldexp(d[c], (int)(u[c] & 1u));
             else if constexpr (OP == OP_CNDMASK) u[c] = (u[c] & 1u) ? u[c] + 7u : u[c] >> 1;
             else if constexpr (OP == OP_BITOP3) u[c] = __builtin_amdgcn_bitop3_b32(u[c], u[(c + 3) & 7], (uint32_t)r, 0x96);
+            else if constexpr (OP == OP_PKMUL32) p[c] = p[c] * f2{1.0000001f, 0.999999f};
+            else if constexpr (OP == OP_PKADD32) p[c] = p[c] + f2{1.0000001f, 0.999999f};
+            else if constexpr (OP == OP_MUL32) f[c] = f[c] * 1.0000001f;
+            else if constexpr (OP == OP_ADD32) f[c] = f[c] + 1.0000001f;
+            else if constexpr (OP == OP_CVT_F32_I32) { f[c] = (float)(int32_t)u[c]; u[c] = u[c] * 3u + __builtin_bit_cast(uint32_t, f[c]); }
+            else if constexpr (OP == OP_CVT_I32_F32) { u[c] = (uint32_t)(int32_t)f[c]; f[c] = f[c] + __builtin_bit_cast(float, (u[c] & 0xffu) | 0x3f800000u); }
+            else if constexpr (OP == OP_FLOOR32) f[c] = __builtin_floorf(f[c]) + 0.5f;
+            else if constexpr (OP == OP_FRACT32) f[c] = __builtin_amdgcn_fractf(f[c]) + 1.5f;
+            else if constexpr (OP == OP_CMPSEL32) f[c] = f[c] > 1.5f ? f[c] * 0.5f : f[c] + 0.75f;
+            else if constexpr (OP == OP_MED3) f[c] = __builtin_amdgcn_fmed3f(f[c], 0.25f, 3.0f) + 0.37f;
+            else if constexpr (OP == OP_LDS_RAND) { u[c] = lds[(u[c] >> 3) & 255u] + u[c]; }
+            else if constexpr (OP == OP_SQRT32_RN) f[c] = sqrt_rn(f[c]) + 2.0f;
+            else if constexpr (OP == OP_DIV32_RN) f[c] = div_rn(3.0f, f[c]) + 1.0f;
+            else if constexpr (OP == OP_MAD_U32_U24) u[c] = (u[c] & 0xffffffu) * 0x51F53u + 1u;
+            else if constexpr (OP == OP_ADD3) u[c] = u[c] + u[(c + 3) & 7] + (uint32_t)r;
             else if constexpr (OP == OP_XOR2) { uint32_t t = u[c] ^ u[(c + 3) & 7]; asm volatile("" : "+v"(t)); u[c] = t ^ (uint32_t)r; }
         }
     }
@@ -217,6 +235,8 @@ int main()
         OPT(OP_FMA64, 1); OPT(OP_MUL64, 1); OPT(OP_ADD64, 1); OPT(OP_FMA32, 1); OPT(OP_PKFMA32, 1); OPT(OP_MAD64, 1); OPT(OP_MULLO, 2); OPT(OP_MULHI, 2);
         OPT(OP_XOR, 3); OPT(OP_RCP32, 2); OPT(OP_SQRT32, 2); OPT(OP_LOG32, 2); OPT(OP_RCP64, 2); OPT(OP_CVT_F64_U32, 3); OPT(OP_CVT_F32_F64, 3);
         OPT(OP_FLOOR64, 2); OPT(OP_LDEXP64, 2); OPT(OP_CNDMASK, 4); OPT(OP_BITOP3, 1); OPT(OP_XOR2, 2);
+        OPT(OP_PKMUL32, 1); OPT(OP_PKADD32, 1); OPT(OP_MUL32, 1); OPT(OP_ADD32, 1); OPT(OP_CVT_F32_I32, 3); OPT(OP_CVT_I32_F32, 4); OPT(OP_FLOOR32, 2); OPT(OP_FRACT32, 2);
+        OPT(OP_CMPSEL32, 4); OPT(OP_MED3, 2); OPT(OP_LDS_RAND, 4); OPT(OP_SQRT32_RN, 10); OPT(OP_DIV32_RN, 9); OPT(OP_MAD_U32_U24, 2); OPT(OP_ADD3, 1);
     }
     {
         unsigned int* st; unsigned long long* cnt;
