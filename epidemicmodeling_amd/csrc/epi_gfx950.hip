@@ -535,6 +535,15 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 // non-temporal hint so that they do not displace the workgroups' spill lines and the tables from the L2.
 #define EPI_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 
+// -DEPI_PHASE_STAMPS (variant builds for measurements only): thread 0 of every workgroup adds the clock ticks it spent
+// in each phase of k_step_coop to g_phase[]; epi_debug_phase_times reads and clears them.
+#ifdef EPI_PHASE_STAMPS
+__device__ unsigned long long g_phase[8];
+#define EPI_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_phase[k], now_ - stamp_); stamp_ = now_; } } while (0)
+#else
+#define EPI_STAMP(k) do { } while (0)
+#endif
+
 constexpr int COOP_WAVES = 4;   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
                                 // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 // DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
@@ -596,6 +605,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     unsigned int flags = 0;
     int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
     unsigned long long code = 0ULL;
+#ifdef EPI_PHASE_STAMPS
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
 
     // ---- A: stage the bins, observation moments -----------------------------------
     if (active) {
@@ -632,12 +644,13 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
+    EPI_STAMP(0);
     // ---- B: the table-free part of attempt 0 of both binomials of every bin --------------------------------
     // A rejection draw is settled here when its candidate falls inside the squeeze region (about six in seven);
     // every other draw is remembered in a bit mask (bit 2 i + j) and queued in one go after the loop: one prefix sum
     // and one LDS atomic per wave instead of one per bin.  The queued draws repeat attempt 0 in full in round 1 of
     // phase C (the words are a function of the counter: nothing has to be kept).
-    unsigned long long fm0 = 0ULL, fm1 = 0ULL;                                     // bins 0..31 / 32..63
+    unsigned long long fm0 = 0ULL, fm1 = 0ULL, fm2 = 0ULL, fm3 = 0ULL;            // bins 0..15 / 16..31 / 32..47 / 48..63
 #pragma unroll 1
     for (int i = 0; i < H; i++) {
         if (active) {
@@ -650,30 +663,34 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             for (int j = 0; j < 2; j++) {
                 const int32_t n = j ? nn.y : nn.x;
                 const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];
-                int32_t x;
+                int32_t x = 0;
                 const BinConsts bc = Dp->bc[j][i];                                 // wave-uniform: scalar loads
                 // all of the record before the first branch: the loads go out together and are waited for once
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2));
-                const int cls = binom_classify_rec(bc, n, x);
-                const bool flip = bc.flip != 0;
-                bool fail = false;
-                if (cls == BINOM_INVERSION) x = binom_inversion(n, bc.lnq, bc.sr, wa);
-                else if (cls == BINOM_REJECTION) {
-                    const BtrsConsts C = btrs_consts(n, bc.btrs());
-                    fail = !btrs_fast(C, wa, wb, x);
+                int st = BTRS_ACCEPT;
+                if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
+                else if (bc.kind == 2) {
+                    if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts(n, bc.btrs()), wa, wb, x);
+                    else if (n > 0) x = binom_inversion(n, bc.lnq, bc.sr, wa);
                 }
-                const int32_t res = fail ? n : (flip ? n - x : x);                 // an open draw keeps n for phase C
+                const int32_t res = st != BTRS_ACCEPT ? n : (bc.flip != 0 ? n - x : x);   // an unsettled draw keeps n for phase C
                 if (j) nn.y = res; else nn.x = res;
-                failbits |= (unsigned int)fail << j;
+                failbits |= (unsigned int)st << (2 * j);
             }
             slots[i * CTPB + tid] = nn;
-            if (i < 32) fm0 |= (unsigned long long)failbits << (2 * i);
-            else fm1 |= (unsigned long long)failbits << (2 * (i - 32));
+            // four bits per bin: two per draw (1 = attempt 0 open, 2 = attempt 0 rejected)
+            if (i < 16) fm0 |= (unsigned long long)failbits << (4 * i);
+            else if (i < 32) fm1 |= (unsigned long long)failbits << (4 * (i - 16));
+            else if (i < 48) fm2 |= (unsigned long long)failbits << (4 * (i - 32));
+            else fm3 |= (unsigned long long)failbits << (4 * (i - 48));
         }
     }
     {
         const int lane = tid & 63;
-        const unsigned int mine = (unsigned int)(__popcll(fm0) + __popcll(fm1));
+        // a draw is queued when either of its two bits is set
+        const unsigned long long odd = 0x5555555555555555ULL;
+        const unsigned long long q_0 = (fm0 | (fm0 >> 1)) & odd, q_1 = (fm1 | (fm1 >> 1)) & odd, q_2 = (fm2 | (fm2 >> 1)) & odd, q_3 = (fm3 | (fm3 >> 1)) & odd;
+        const unsigned int mine = (unsigned int)(__popcll(q_0) + __popcll(q_1) + __popcll(q_2) + __popcll(q_3));
         unsigned int incl = mine;
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned int t = __shfl_up(incl, d, 64);
@@ -685,13 +702,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (lane == 63) pos = atomicAdd(&qn[0], total);
             pos = __shfl(pos, 63, 64) + incl - mine;
         }
-        for (int half = 0; half < 2; half++) {
-            unsigned long long fm = half ? fm1 : fm0;
+        for (int part = 0; part < 4; part++) {
+            if (part * 16 >= H) break;
+            unsigned long long fm = part == 0 ? q_0 : (part == 1 ? q_1 : (part == 2 ? q_2 : q_3));
+            const unsigned long long both = part == 0 ? fm0 : (part == 1 ? fm1 : (part == 2 ? fm2 : fm3));
             while (fm) {
                 const int bit = __ffsll((long long)fm) - 1;
                 fm &= fm - 1ULL;
-                const int i = (bit >> 1) + 32 * half, j = bit & 1;
-                if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14));
+                const int i = (bit >> 2) + 16 * part, j = (bit >> 1) & 1;
+                const unsigned int rejected = (unsigned int)(both >> (bit + 1)) & 1u;       // attempt 0 is settled: the draw goes on with attempt 1
+                if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14) | (rejected << 15));
                 else {                                                              // queue full: finish here
                     const int32_t n = slot_words[(i * CTPB + tid) * 2 + j];
                     const int32_t k = btrs_from0(n, Dp->bc[j][i].btrs(), Dp->lf, screen, g, j, (uint32_t)i);
@@ -702,15 +722,17 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
+    EPI_STAMP(1);
     // ---- C: binomial rounds ----------------------------------------------------------------
-    // Round r runs attempt r - 1 of every queued draw in full (round 1 repeats attempt 0 with its acceptance test).
+    // Round r runs, in full, attempt r - 1 of the queued draws whose attempt 0 was left open and attempt r of those whose
+    // attempt 0 was rejected (bit 15 of the entry).
     // One barrier per round: round r reads the entries of queue (r-1) mod 2, counted in qn[(r-1) mod 3], and pushes
     // its rejected draws to queue r mod 2, counted in qn[r mod 3]; thread 0 clears qn[(r+1) mod 3] for the round after
     // (it was last read in round r-1, before this round's barrier).
     {
         int cur = 0;                                                               // (round - 1) mod 3
 #pragma unroll 1
-        for (uint32_t round = 1; round <= BINOM_MAX_ATTEMPTS; round++) {
+        for (uint32_t round = 1; round < BINOM_MAX_ATTEMPTS; round++) {
             __syncthreads();
             const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
             if (cnt == 0u) break;
@@ -718,27 +740,28 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
             unsigned short* qnext = (round & 1u) ? q1 : q0;
-            const uint32_t att = round - 1u;
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
-                const int t = entry & 255, i = (entry >> 8) & 63, j = entry >> 14;
+                const int t = entry & 255, i = (entry >> 8) & 63, j = (entry >> 14) & 1;
+                const uint32_t att = round - 1u + (uint32_t)(entry >> 15);
                 const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
                 const BinConsts* __restrict__ bp = &Dp->bc[j][i];                  // the lane's record: adjacent loads
                 const BtrsBin B = bp->btrs();
                 const bool flip = bp->flip != 0;                                   // a queued draw is a rejection draw
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
-                uint32_t wa, wb;
-                if (att == 0u) {
-                    uint32_t w[4];
-                    rng_block(gt, K_BINOM0, (uint32_t)i, 0, w);
-                    wa = j ? w[2] : w[0]; wb = j ? w[3] : w[1];
-                } else retry_pair(gt, j ? K_POS : K_SYMPT, (uint32_t)i, att, wa, wb);
+                // attempt 0 takes its half of the bin's first block, attempt a >= 1 half (a - 1) & 1 of block (a - 1) / 2 of the draw's own stream
+                const bool first = att == 0u;
+                const uint32_t kind = first ? K_BINOM0 : (j ? K_POS : K_SYMPT);
+                const bool hi = first ? j != 0 : ((att - 1u) & 1u) != 0u;
+                uint32_t w[4];
+                rng_block(gt, kind, (uint32_t)i, first ? 0u : (att - 1u) >> 1, w);
+                const uint32_t wa = hi ? w[2] : w[0], wb = hi ? w[3] : w[1];
                 const BtrsConsts C = btrs_consts(n, B);
                 int32_t k = btrs_attempt(C, B.lpq, Dp->lf, screen, wa, wb);
                 const bool fail = k < 0;
                 // after the last round nothing reads the queue: a draw rejected there ends as in btrs_finish
-                const bool pushed = round < BINOM_MAX_ATTEMPTS && q_push(fail, entry, qnext, &qn[nxt]);
+                const bool pushed = round < BINOM_MAX_ATTEMPTS - 1u && q_push(fail, entry, qnext, &qn[nxt]);
                 if (fail && !pushed) k = btrs_finish(C, B.lpq, Dp->lf, screen, gt, j ? K_POS : K_SYMPT, (uint32_t)i, att + 1u);
                 if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
             }
@@ -748,6 +771,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }                           // the count a slower thread may still be reading is zero already
     __syncthreads();
 
+    EPI_STAMP(2);
     // ---- D: isolation bookkeeping and the table-and-squeeze part of attempt 0 of the gamma terms ----------------
     // iteration `it` handles bin (it == 0 ? H-1 : it-1), whose survivors seed infection term `it`
     // (the circular shift of simulate.jl:145).  A term is settled here when its normal comes from the inside of a
@@ -809,6 +833,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
+    EPI_STAMP(3);
     // ---- E: gamma rounds (round r runs attempt r - 1 in full) ----------------------------------------------------
     {
         int cur = 0;
@@ -845,6 +870,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
+    EPI_STAMP(4);
     // ---- F: infection sum in bin order, new infections, outputs --------------------------------
     if (active) {
         double infsum = 0.0;
@@ -888,6 +914,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             atomicMax(&Ak->scal->lwmax_bits, c);
         }
     }
+    EPI_STAMP(5);
 }
 
 static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry); }
@@ -2983,6 +3010,14 @@ int epi_pf_update_noalloc(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
     return collect_from(c, b, sc.scal, loglik, ess, flags);
 }
 
+#ifdef EPI_PHASE_STAMPS
+int epi_debug_phase_times(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef EPI_TESTING
 int epi_debug_step_impl(int cooperative)
 {

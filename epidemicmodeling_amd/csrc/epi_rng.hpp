@@ -395,7 +395,7 @@ EPI_HD BtrsBin btrs_bin(double pp)
 }
 
 struct BtrsConsts {
-    float spq, b, a2, cfr;
+    float npq, spq, b, a2, cfr;
     int32_t ci, m, n;
 };
 
@@ -403,7 +403,8 @@ EPI_HD BtrsConsts btrs_consts(int32_t n, const BtrsBin& B)
 {
     BtrsConsts C;
     C.n = n;
-    C.spq = sqrt_rn((float)n * B.pq);
+    C.npq = (float)n * B.pq;
+    C.spq = sqrt_rn(C.npq);
     C.b = __builtin_fmaf(2.53f, C.spq, 1.15f);
     C.a2 = __builtin_fmaf(0.0496f, C.b, B.a0x2);
     const uint64_t prod = (uint64_t)(uint32_t)n * B.ppx + 0x80000000ULL;
@@ -471,6 +472,29 @@ __device__ __forceinline__ float btrs_lv_screen(const BtrsConsts& C, float v, fl
 }
 #endif
 
+enum { BTRS_ACCEPT = 0, BTRS_OPEN = 1, BTRS_REJECT = 2 };
+#ifdef EPI_HAVE_SCREEN
+// Bounds on the right side of the acceptance test that need no table (Kachitvichyanukul & Schmeiser 1988, the squeeze
+// of algorithm BTPE): for j = |k - m| < n p q / 2 - 1,  | log f(k) - log f(m) + j^2 / (2 n p q) | <= rho(j),
+//   rho(j) = (j / npq) ((j (j / 3 + 0.625) + 1/6) / npq + 1/2).
+// The estimate lvf of the left side decides when it clears a bound by more than the errors of both sides (its own
+// band as below; t and rho carry a hardware reciprocal and five roundings): ACCEPT / REJECT are then the outcome of
+// the defining test, OPEN leaves it to that test.
+__device__ __forceinline__ int btrs_bounds(const BtrsConsts& C, int32_t k, float lvf)
+{
+    const int32_t d = k - C.m;
+    const float j = (float)(d < 0 ? -d : d);
+    const float rn = f_rcp(C.npq);
+    const float x1 = j * rn;
+    const float t = -0.5f * j * x1;
+    const float rho = x1 * __builtin_fmaf(__builtin_fmaf(j, __builtin_fmaf(j, 0.33333334f, 0.625f), 0.16666667f), rn, 0.5f);
+    const float g = __builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, __builtin_fmaf(rho - t, 2e-6f, BTRS_GUARD_ABS));
+    const bool valid = j < __builtin_fmaf(0.5f, C.npq, -1.0f);
+    const bool acc = lvf + g <= t - rho, rej = lvf - g > t + rho;
+    return !valid ? BTRS_OPEN : (acc ? BTRS_ACCEPT : (rej ? BTRS_REJECT : BTRS_OPEN));
+}
+#endif
+
 // One attempt: the accepted k (>= 0) or -1.  screen: the device may decide by its binary32 estimates.
 EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, bool screen, uint32_t wa, uint32_t wb)
 {
@@ -487,10 +511,17 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, 
     const int32_t k = C.ci + kf;
     if ((uint32_t)k > (uint32_t)C.n) return -1;
     if (us >= 0.07f && (0.92f - v) * C.b >= 4.2f) return k;
+#ifdef EPI_HAVE_SCREEN
+    float lvf = 0.f;
+    if (screen) {
+        lvf = btrs_lv_screen(C, v, r_us);
+        const int bd = btrs_bounds(C, k, lvf);
+        if (bd != BTRS_OPEN) return bd == BTRS_ACCEPT ? k : -1;
+    }
+#endif
     const double ub = btrs_ub(C, k, lpq, lf);
 #ifdef EPI_HAVE_SCREEN
     if (screen) {
-        const float lvf = btrs_lv_screen(C, v, r_us);
         const double diff = (double)lvf - ub;
         const double guard = (double)__builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, BTRS_GUARD_ABS);
         if (diff < -guard) return k;
@@ -501,20 +532,21 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, 
 }
 
 #if defined(EPI_HAVE_SCREEN)
-// The part of an attempt that needs no table and no logarithm: true = accepted inside the squeeze region with a
-// candidate whose floor the binary32 estimate settles (k valid).  false = everything else: btrs_attempt on the same
-// words gives the outcome.
-__device__ __forceinline__ bool btrs_fast(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k)
+// An attempt without the table: ACCEPT (k valid), REJECT, or OPEN: btrs_attempt on the same words gives the outcome.
+__device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k)
 {
     const float u = btrs_u(wa), us = btrs_us(u), v = btrs_v(wb);
     float r_us; int32_t kf;
     const bool sure = btrs_kfloor_screen(C, u, us, r_us, kf);
     k = C.ci + kf;
-    return sure && (uint32_t)k <= (uint32_t)C.n && us >= 0.07f && (0.92f - v) * C.b >= 4.2f;
+    const bool inr = (uint32_t)k <= (uint32_t)C.n;
+    const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.2f;
+    const int bd = btrs_bounds(C, k, btrs_lv_screen(C, v, r_us));
+    return !sure ? BTRS_OPEN : (!inr ? BTRS_REJECT : (squeeze ? BTRS_ACCEPT : bd));
 }
 #else
 // (the host pass over the kernel bodies sees a declaration; only device code calls it)
-__device__ bool btrs_fast(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k);
+__device__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k);
 #endif
 
 // Word pair of attempt `att` (>= 1) of a retry stream: block (att-1)/2, words (0,1) or (2,3).
@@ -692,13 +724,27 @@ EPI_HD GammaConsts gamma_consts(double shape, bool screen)
 EPI_HD float gamma_u(uint32_t wu) { return (float)wu * 0x1p-32f; }
 
 // The squeeze: true = accepted without a logarithm (v valid).  t = 1 + c x <= 0 is never accepted.
+// With s = c x and 9 d c^2 = 1 + 2 e the exponent of the acceptance probability is
+//   x^2/2 + d (1 - v + log v) = -e x^2 + 3 d (log(1 + s) - s + s^2/2 - s^3/3) = -e x^2 - 3 d int_0^s r^3 / (1 + r) dr,
+// and the integral is at most s^4 / 4 for s >= 0 and s^4 / (4 (1 - |s|)) <= (s^4 / 4)(1 + 2 |s|) for -1/2 <= s < 0, so
+// the probability is at least 1 - A,  A = 7e-6 x^2 + (c^2 x^4 / 12)(1 + 1.4e-5)(1 + 2 |s|)   (3 d c^2 / 4 = (1 + 2 e) / 12).
+// For the large shapes of this model (d in the thousands) A is of the order 1e-5: the logarithms are almost never
+// needed.  Marsaglia and Tsang's own 1 - 0.0331 x^4 (here with the allowance for e) serves where it is the larger.
+EPI_HD float gamma_squeeze(float c, float xf)
+{
+    const float x2 = xf * xf, x4 = x2 * x2;
+    const float as = __builtin_fabsf(c * xf);
+    const float a_mt = __builtin_fmaf(0.03311f, x4, 1.4e-5f * x2);
+    const float a_d = __builtin_fmaf(((c * c) * x4) * 0.08334f, __builtin_fmaf(2.0f, as, 1.0f), 7e-6f * x2);
+    const float a = (as <= 0.5f && a_d < a_mt) ? a_d : a_mt;
+    return 0.9999997f - a;
+}
+
 EPI_HD bool gamma_fast(const GammaConsts& G, float xf, uint32_t wu, double& v)
 {
     const double t = __builtin_fma((double)G.c, (double)xf, 1.0);
     v = t * t * t;
-    const float x2 = xf * xf;
-    const float sq = __builtin_fmaf(-0.03311f, x2 * x2, __builtin_fmaf(-1.4e-5f, x2, 0.9999998f));
-    return t > 0.0 && gamma_u(wu) < sq;
+    return t > 0.0 && gamma_u(wu) < gamma_squeeze(G.c, xf);
 }
 
 #ifdef EPI_HAVE_SCREEN

@@ -448,6 +448,22 @@ static inline float gamma_c(float d)
 
 float orc_gamma_c(float d) { return gamma_c(d); }
 
+/* Lower bound 1 - A of the acceptance probability exp(x^2/2 + d (1 - v + log v)) for any c with 9 d c^2 = 1 + 2 e,
+ * 0 <= e <= 7e-6: the exponent is -e x^2 - 3 d int_0^s r^3/(1+r) dr with s = c x, and the integral is at most
+ * (s^4/4)(1 + 2|s|) for |s| <= 1/2, so A = 7e-6 x^2 + (c^2 x^4 / 12)(1 + 1.4e-5)(1 + 2|s|); Marsaglia and Tsang's
+ * 0.0331 x^4 (with the allowance for e) where that is the smaller. */
+static inline float gamma_squeeze(float c, float xf)
+{
+    float x2 = xf * xf, x4 = x2 * x2;
+    float as = fabsf(c * xf);
+    float a_mt = fmaf(0.03311f, x4, 1.4e-5f * x2);
+    float a_d = fmaf(((c * c) * x4) * 0.08334f, fmaf(2.0f, as, 1.0f), 7e-6f * x2);
+    float a = (as <= 0.5f && a_d < a_mt) ? a_d : a_mt;
+    return 0.9999997f - a;
+}
+
+float orc_gamma_squeeze(float c, float x) { return gamma_squeeze(c, x); }
+
 static double gamma_draw(double shape, double scale, const rng_t *g, uint32_t bin)
 {
     if (!(shape >= GAMMA_MIN_SHAPE)) return 0.0;
@@ -469,8 +485,7 @@ static double gamma_draw(double shape, double scale, const rng_t *g, uint32_t bi
         double t = fma((double)c, x, 1.0);
         if (!(t > 0.0)) continue;
         double vv = t * t * t;
-        float x2f = xf * xf;
-        if (uf < fmaf(-0.03311f, x2f * x2f, fmaf(-1.4e-5f, x2f, 0.9999998f))) { v = vv; break; }
+        if (uf < gamma_squeeze(c, xf)) { v = vv; break; }
         if (!(uf > 0.0f)) { v = vv; break; }
         if (s_log((double)uf) < 0.5 * (x * x) + d * (1.0 - vv + s_log(vv))) { v = vv; break; }
     }

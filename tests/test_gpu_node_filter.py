@@ -44,7 +44,9 @@ def test_node_filter_bit_exact(delay, G):
         moved.append(got["moved"])
         _, mu, _ = orc.log_weights(st, 0.2, 0)
     if G > 1:
-        assert max(moved) > n // G                     # some shard sent more than it holds
+        # the far-out observation leaves nearly all weight in one shard, which then sends (nearly) every slot the other
+        # shards own: more than it holds itself once there are three shards or more
+        assert max(moved) > (n // G if G > 2 else 0.95 * (n // G))
     else:
         assert moved == [0, 0, 0]
     eS, eI, eR, eT, bad = orc.mean(st)
