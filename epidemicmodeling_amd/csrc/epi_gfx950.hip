@@ -477,8 +477,13 @@ __global__ __launch_bounds__(64) void k_step_one(const StepArgs A, const DevPara
 //   F  infection sum in bin order, new infections, outputs
 // LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues + three rotating entry counts.
 // ---------------------------------------------------------------------------
-constexpr int CTPB = 256;                        // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
-constexpr unsigned int QCAP = 2048;              // entries per retry queue
+#ifndef EPI_CTPB
+#define EPI_CTPB 256
+#endif
+constexpr int CTPB = EPI_CTPB;                   // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
+constexpr unsigned int QCAP = 8 * CTPB;          // entries of the first retry queue (what the first-attempt phases leave open; rounds 2, 4, ... write it again)
+constexpr unsigned int QCAP1 = 4 * CTPB;         // entries of the second one (what round 1, 3, ... leave open: a fraction of their input)
+static_assert(CTPB == 64 || CTPB == 128 || CTPB == 256, "whole wavefronts, 8 bits of thread index, rows padded to 256 particles");
 
 // Binary64 square root for arguments that are zero or at least 2^-767: the compiler's own expansion (reciprocal
 // square root estimate, one coupled Goldschmidt step, two residual corrections) without the pre- and post-scaling by
@@ -506,6 +511,15 @@ __device__ __noinline__ int32_t btrs_from0(int32_t n, const BtrsBin B, const LfT
     const int32_t k = btrs_attempt(C, B.lpq, lf, screen, j ? w[2] : w[0], j ? w[3] : w[1]);
     return k >= 0 ? k : btrs_finish(C, B.lpq, lf, screen, g, j ? K_POS : K_SYMPT, bin, 1u);
 }
+// the remaining attempts of a rejection draw in one thread; one attempt for an n beyond the log-factorial table
+__device__ __noinline__ int32_t btrs_finish_thread(const BtrsConsts C, double lpq, const LfTable lf, bool screen, const Rng g, uint32_t kind, uint32_t bin, uint32_t att)
+{
+    return btrs_finish(C, lpq, lf, screen, g, kind, bin, att);
+}
+__device__ __noinline__ int32_t btrs_attempt_far(const BtrsConsts C, double lpq, const LfTable lf, bool screen, uint32_t wa, uint32_t wb)
+{
+    return btrs_attempt(C, lpq, lf, screen, wa, wb);
+}
 // an infection term from attempt 0 on in one thread
 __device__ __noinline__ double gamma_from0(double shape, double scale, const ZigTable* __restrict__ Z, const Rng g, uint32_t term, bool screen)
 {
@@ -514,8 +528,12 @@ __device__ __noinline__ double gamma_from0(double shape, double scale, const Zig
     return gamma_draw(shape, scale, wz, wu, Z, g, term, screen);
 }
 
+// what a retry round reads of a (draw, bin) record, kept in LDS
+struct alignas(8) CoopRec { double lpq; uint32_t ppx; float pq, a0x2; int32_t flip; };
+static_assert(sizeof(CoopRec) == 24, "three 8-byte words");
+
 // push `entry` for every lane that wants to (one LDS atomic per wave); false = queue full
-__device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn)
+__device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn, unsigned int cap)
 {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ULL) return true;
@@ -526,7 +544,7 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
     base = __shfl(base, leader, 64);
     if (!want) return true;
     const unsigned int pos = base + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
-    if (pos >= QCAP) return false;
+    if (pos >= cap) return false;
     q[pos] = entry;
     return true;
 }
@@ -538,12 +556,17 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 // -DEPI_PHASE_STAMPS (variant builds for measurements only): thread 0 of every workgroup adds the clock ticks it spent
 // in each phase of k_step_coop to g_phase[]; epi_debug_phase_times reads and clears them.
 #ifdef EPI_PHASE_STAMPS
-__device__ unsigned long long g_phase[8];
+__device__ unsigned long long g_phase[16];
 #define EPI_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_phase[k], now_ - stamp_); stamp_ = now_; } } while (0)
 #else
 #define EPI_STAMP(k) do { } while (0)
 #endif
 
+#ifndef EPI_X_CUT
+#define EPI_X_CUT 0
+#endif
+constexpr uint32_t COOP_BINOM_ROUNDS = 3;   // cooperative rounds of the binomial retries; what is still open after them (about one draw in
+                                            // a thousand) is finished by the thread that holds it, without further barriers
 constexpr int COOP_WAVES = 4;   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
                                 // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 // DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
@@ -569,9 +592,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     double* gslots = reinterpret_cast<double*>(smem);                              // [H][CTPB]: gamma term of the bin's survivors
     unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * CTPB * 8);
     unsigned short* q1 = q0 + QCAP;
-    unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP);                 // qn[0..2]: entry counts, rotating (+ 1 pad)
+    unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP1);                 // qn[0..2]: entry counts, rotating (+ 1 pad)
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
     ZigEntry* ztab = reinterpret_cast<ZigEntry*>(s_max + CTPB / 64);               // [ZIG_N]: strips of the normal generator
+    CoopRec* crec = reinterpret_cast<CoopRec*>(ztab + ZIG_N);                       // [2][H]: per-(draw, bin) constants for the retry rounds
 
     const int tid = threadIdx.x;
     const int64_t base = ((int64_t)xcd_tile() + A.block0) * CTPB;
@@ -598,6 +622,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[tid], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
     if (tid < ZIG_N) ztab[tid] = Dp->zig.e[tid];
+    for (int r = tid; r < 2 * H; r += CTPB) {
+        const BinConsts& bc = Dp->bc[r >= H][r >= H ? r - H : r];
+        crec[r] = CoopRec{bc.lpq, bc.ppx, bc.pq, bc.a0x2, bc.flip};
+    }
     // the cleared counts and the strips must be visible before any wave pushes to the queue (after phase B): the barrier stands here,
     // where the waves of the workgroup still run together, and not between phases A and B, which only exchange data
     // within a thread
@@ -668,13 +696,20 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 // all of the record before the first branch: the loads go out together and are waited for once
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2));
                 int st = BTRS_ACCEPT;
+#ifdef EPI_X_SKIP_B
+                if (false) {}
+#else
                 if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
+#endif
                 else if (bc.kind == 2) {
                     if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts(n, bc.btrs()), wa, wb, x);
                     else if (n > 0) x = binom_inversion(n, bc.lnq, bc.sr, wa);
                 }
                 const int32_t res = st != BTRS_ACCEPT ? n : (bc.flip != 0 ? n - x : x);   // an unsettled draw keeps n for phase C
                 if (j) nn.y = res; else nn.x = res;
+#ifdef EPI_X_SKIP_C
+                st = BTRS_ACCEPT;
+#endif
                 failbits |= (unsigned int)st << (2 * j);
             }
             slots[i * CTPB + tid] = nn;
@@ -731,11 +766,17 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // (it was last read in round r-1, before this round's barrier).
     {
         int cur = 0;                                                               // (round - 1) mod 3
+        const double* __restrict__ lf_t = Dp->lf.t;
+        const int32_t lf_n = Dp->lf.n;
 #pragma unroll 1
-        for (uint32_t round = 1; round < BINOM_MAX_ATTEMPTS; round++) {
+        for (uint32_t round = 1; round <= COOP_BINOM_ROUNDS; round++) {
             __syncthreads();
-            const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
+            const unsigned int qcap_cur = (round & 1u) ? QCAP : QCAP1, qcap_next = (round & 1u) ? QCAP1 : QCAP;
+            const unsigned int cnt = qn[cur] < qcap_cur ? qn[cur] : qcap_cur;
             if (cnt == 0u) break;
+#ifdef EPI_PHASE_STAMPS
+            if (tid == 0) { atomicAdd(&g_phase[8], 1ULL); atomicAdd(&g_phase[9], (unsigned long long)cnt); if (round == 1u) atomicAdd(&g_phase[10], (unsigned long long)cnt); if (round == 2u) atomicAdd(&g_phase[11], (unsigned long long)cnt); }
+#endif
             const int nxt = cur == 2 ? 0 : cur + 1;
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
@@ -744,11 +785,17 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             for (unsigned int e = tid; e < cnt; e += CTPB) {
                 const unsigned short entry = q[e];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = (entry >> 14) & 1;
+#ifdef EPI_PHASE_STAMPS
+                if (round == 1u && (entry >> 15)) atomicAdd(&g_phase[15], 1ULL);
+#endif
                 const uint32_t att = round - 1u + (uint32_t)(entry >> 15);
                 const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
-                const BinConsts* __restrict__ bp = &Dp->bc[j][i];                  // the lane's record: adjacent loads
-                const BtrsBin B = bp->btrs();
-                const bool flip = bp->flip != 0;                                   // a queued draw is a rejection draw
+                const CoopRec rec = crec[j * H + i];
+                const BtrsBin B{rec.ppx, rec.pq, rec.a0x2, rec.lpq};
+                const bool flip = rec.flip != 0;                                   // a queued draw is a rejection draw
+#if EPI_X_CUT == 1
+                slot_words[(i * CTPB + t) * 2 + j] = flip ? n : 0; continue;
+#endif
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 // attempt 0 takes its half of the bin's first block, attempt a >= 1 half (a - 1) & 1 of block (a - 1) / 2 of the draw's own stream
                 const bool first = att == 0u;
@@ -757,12 +804,23 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 uint32_t w[4];
                 rng_block(gt, kind, (uint32_t)i, first ? 0u : (att - 1u) >> 1, w);
                 const uint32_t wa = hi ? w[2] : w[0], wb = hi ? w[3] : w[1];
+#if EPI_X_CUT == 2
+                slot_words[(i * CTPB + t) * 2 + j] = (wa ^ wb) & 1; continue;
+#endif
                 const BtrsConsts C = btrs_consts(n, B);
-                int32_t k = btrs_attempt(C, B.lpq, Dp->lf, screen, wa, wb);
+                int32_t k;
+#if EPI_X_CUT == 3
+                slot_words[(i * CTPB + t) * 2 + j] = (int32_t)(C.spq + C.cfr) + C.ci + C.m + ((wa ^ wb) & 1); continue;
+#endif
+                if (n < lf_n) k = btrs_attempt_tab(C, B.lpq, lf_t, screen, wa, wb);
+                else k = btrs_attempt_far(C, B.lpq, LfTable{lf_t, lf_n}, screen, wa, wb);
+#if EPI_X_CUT == 4
+                slot_words[(i * CTPB + t) * 2 + j] = k < 0 ? 0 : k; continue;
+#endif
                 const bool fail = k < 0;
-                // after the last round nothing reads the queue: a draw rejected there ends as in btrs_finish
-                const bool pushed = round < BINOM_MAX_ATTEMPTS - 1u && q_push(fail, entry, qnext, &qn[nxt]);
-                if (fail && !pushed) k = btrs_finish(C, B.lpq, Dp->lf, screen, gt, j ? K_POS : K_SYMPT, (uint32_t)i, att + 1u);
+                // the first rounds hand rejected draws on; after them (and when the queue is full) a draw is finished by the thread that holds it
+                const bool pushed = round < COOP_BINOM_ROUNDS && q_push(fail, entry, qnext, &qn[nxt], qcap_next);
+                if (fail && !pushed) k = btrs_finish_thread(C, B.lpq, LfTable{lf_t, lf_n}, screen, gt, j ? K_POS : K_SYMPT, (uint32_t)i, att + 1u);
                 if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
             }
             cur = nxt;
@@ -777,6 +835,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // (the circular shift of simulate.jl:145).  A term is settled here when its normal comes from the inside of a
     // strip and the squeeze accepts it; the others are queued and repeat attempt 0 in full in round 1 of phase E.
     int32_t sum_inf = 0;
+    unsigned long long g_over = 0ULL;  // terms that found the queue full
     uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
     int32_t I_next = active ? ld_in(1 + H) : 0;                                    // bin H-1; loads run one bin ahead
     int2 sp_next = slots[(H - 1) * CTPB + tid];                                    // so does the read of the bin's slot
@@ -816,32 +875,50 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 rng_block(g, K_GAMMA, (uint32_t)it >> 1, 0, w);
                 wz = w[0]; z_odd = w[1]; wu = w[2]; w_odd = w[3];
             }
+#ifdef EPI_X_SKIP_G
+            if (true) gslots[i * CTPB + tid] = shape;
+#else
             if (gamma_is_zero(shape)) gslots[i * CTPB + tid] = 0.0;
+#endif
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
                 float xf;
                 double v;
                 const bool inside = zig_fast(wz, ztab[wz & 127u], xf);
-                if (gamma_fast(G, xf, wu, v) && inside) gslots[i * CTPB + tid] = gamma_finish(G, v, theta_it, g, (uint32_t)it);
-                else { slots[i * CTPB + tid] = make_int2(Ii, 0); gfail = true; }
+                // (a shape below 1 needs the boost's extra uniform: left to the rounds, which are not this loop's straight code)
+                if (gamma_fast(G, xf, wu, v) && inside && !G.boost) gslots[i * CTPB + tid] = (G.d * v) * theta_it;
+                else {
+#ifdef EPI_X_SKIP_E
+                    gslots[i * CTPB + tid] = 0.0;
+#else
+                    slots[i * CTPB + tid] = make_int2(Ii, 0); gfail = true;
+#endif
+                }
             }
         }
-        const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[0]);
-        if (gfail && !gpushed) {
-            const int32_t Ii = slots[i * CTPB + tid].x;
-            gslots[i * CTPB + tid] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, g, (uint32_t)it, screen);
-        }
+        const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[0], QCAP);
+        if (gfail && !gpushed) g_over |= 1ULL << it;                               // queue full: finished after the loop
+    }
+    while (g_over) {
+        const int it = __ffsll((long long)g_over) - 1;
+        g_over &= g_over - 1ULL;
+        const int i = it == 0 ? H - 1 : it - 1;
+        const int32_t Ii = slots[i * CTPB + tid].x;
+        gslots[i * CTPB + tid] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, g, (uint32_t)it, screen);
     }
 
-    EPI_STAMP(3);
     // ---- E: gamma rounds (round r runs attempt r - 1 in full) ----------------------------------------------------
     {
         int cur = 0;
 #pragma unroll 1
         for (uint32_t round = 1; round <= GAMMA_MAX_ATTEMPTS; round++) {
             __syncthreads();
-            const unsigned int cnt = qn[cur] < QCAP ? qn[cur] : QCAP;
+            const unsigned int qcap_cur = (round & 1u) ? QCAP : QCAP1, qcap_next = (round & 1u) ? QCAP1 : QCAP;
+            const unsigned int cnt = qn[cur] < qcap_cur ? qn[cur] : qcap_cur;
             if (cnt == 0u) break;
+#ifdef EPI_PHASE_STAMPS
+            if (tid == 0) { atomicAdd(&g_phase[12], 1ULL); atomicAdd(&g_phase[13], (unsigned long long)cnt); if (round == 1u) atomicAdd(&g_phase[14], (unsigned long long)cnt); }
+#endif
             const int nxt = cur == 2 ? 0 : cur + 1;
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
@@ -862,7 +939,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 if (!zig_fast(wz, ztab[wz & 127u], xf)) xf = zig_slow(&Dp->zig, gt, (att << 6) | (uint32_t)it, wz);
                 double v;
                 const bool ok = gamma_attempt(G, xf, wu, v);
-                const bool pushed = round < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt]);   // as above: gamma_finish_from's ending
+                const bool pushed = round < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt], qcap_next);   // as above: gamma_finish_from's ending
                 if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
                 else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], &Dp->zig, gt, (uint32_t)it, att + 1u);
             }
@@ -917,7 +994,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     EPI_STAMP(5);
 }
 
-static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + 2 * QCAP * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry); }
+static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + (QCAP + QCAP1) * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry) + 2 * (size_t)H * sizeof(CoopRec); }
 
 // launch the Philox-driven step with the selected implementation
 template <bool WEIGH>
@@ -3013,8 +3090,8 @@ int epi_pf_update_noalloc(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
 #ifdef EPI_PHASE_STAMPS
 int epi_debug_phase_times(unsigned long long* out)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long z[16] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif

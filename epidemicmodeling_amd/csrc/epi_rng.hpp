@@ -1,7 +1,7 @@
 // Counter-based random variates for the gfx950 particle kernels.
 //
 // Every variate is a pure function of (seed, global particle slot, step,
-// stream tag, attempt): a Philox4x32-10 block addressed by
+// stream tag, attempt): a Philox4x32-7 block addressed by
 //   key     = (seed lo, seed hi)
 //   counter = (slot lo, slot hi, step, kind << 24 | bin << 8 | blk)
 // so results do not depend on launch geometry, sharding or execution order.
@@ -63,12 +63,18 @@ EPI_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
 #endif
 }
 
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11).
-EPI_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+// Philox4x32 (Salmon, Moraes, Dror, Shaw, SC'11) with 7 rounds: the round count the authors report as the smallest
+// that passes BigCrush (their default of 10 adds a safety margin; three rounds are 30 % of the generator's cost, and
+// the generator is a fifth of the step kernel's).  The round function is checked with the published 7- and 10-round
+// known-answer vectors.
+EPI_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                           uint32_t k0, uint32_t k1, uint32_t (&w)[4])
 {
+#ifndef EPI_PHILOX_ROUNDS
+#define EPI_PHILOX_ROUNDS 7
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < EPI_PHILOX_ROUNDS; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         // round 0 mixes wave-uniform words (step, stream tag, key): plain operators let the compiler keep those
@@ -85,7 +91,7 @@ EPI_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 
 EPI_HD void rng_block(const Rng& g, uint32_t kind, uint32_t bin, uint32_t blk, uint32_t (&w)[4])
 {
-    philox4x32_10(g.c0, g.c1, g.c2, (kind << 24) | (bin << 8) | blk, g.k0, g.k1, w);
+    philox4x32(g.c0, g.c1, g.c2, (kind << 24) | (bin << 8) | blk, g.k0, g.k1, w);
 }
 
 // uniform in (0,1): (w + 1/2) 2^-32, exact in binary64
@@ -519,6 +525,9 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, 
         if (bd != BTRS_OPEN) return bd == BTRS_ACCEPT ? k : -1;
     }
 #endif
+#ifdef EPI_X_NO_TABLE
+    return k;
+#endif
     const double ub = btrs_ub(C, k, lpq, lf);
 #ifdef EPI_HAVE_SCREEN
     if (screen) {
@@ -532,6 +541,40 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, 
 }
 
 #if defined(EPI_HAVE_SCREEN)
+// One attempt in the order that suits a pass in which most lanes need the acceptance test, for n inside the log-factorial
+// table (n < lf.n): the four loads go out as soon as the candidate is known (an out-of-range candidate reads entry 0 and
+// is rejected afterwards) and the squeeze and the estimate of the left side are computed while they are in flight.
+// Same decisions as btrs_attempt.
+__device__ __forceinline__ int32_t btrs_attempt_tab(const BtrsConsts& C, double lpq, const double* __restrict__ lf_t, bool screen, uint32_t wa, uint32_t wb)
+{
+    const float u = btrs_u(wa), us = btrs_us(u), v = btrs_v(wb);
+    float r_us; int32_t kf;
+    const bool sure = btrs_kfloor_screen(C, u, us, r_us, kf);
+    if (!(screen && sure)) kf = btrs_kfloor_exact(C.a2, C.b, C.cfr, u, us);
+    const int32_t k = C.ci + kf;
+    const bool inr = (uint32_t)k <= (uint32_t)C.n;
+    const uint32_t ki = inr ? (uint32_t)k : 0u, ni = (uint32_t)C.n, mi = (uint32_t)C.m;
+    // global address space and unsigned 32-bit indices: base in scalar registers + 32-bit offset (the table holds 2^20 doubles)
+    typedef const char __attribute__((address_space(1)))* GlobalBytes;
+    typedef const double __attribute__((address_space(1)))* GlobalDoubles;
+    const GlobalBytes t = (GlobalBytes)lf_t;
+    const double t0 = *(GlobalDoubles)(t + (mi << 3)), t1 = *(GlobalDoubles)(t + ((ni - mi) << 3));
+    const double t2 = *(GlobalDoubles)(t + (ki << 3)), t3 = *(GlobalDoubles)(t + ((ni - ki) << 3));
+    __builtin_amdgcn_sched_barrier(0);                                          // nothing below moves above the loads
+    const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.2f;
+    const float lvf = btrs_lv_screen(C, v, r_us);
+    const float grel = screen ? BTRS_GUARD_REL : __builtin_inff(), gabs = screen ? BTRS_GUARD_ABS : __builtin_inff();
+    const double guard = (double)__builtin_fmaf(__builtin_fabsf(lvf), grel, gabs);
+    const double ub = ((t0 + t1) - (t2 + t3)) + (double)(k - C.m) * lpq;
+    const double diff = (double)lvf - ub;
+    const bool acc = squeeze || diff < -guard;
+    int32_t res = (inr && acc) ? k : -1;
+    if (inr && !acc && !(diff > guard)) res = btrs_lv(v, us, C.a2, C.b, C.spq) <= ub ? k : -1;
+    return res;
+}
+#endif
+
+#if defined(EPI_HAVE_SCREEN)
 // An attempt without the table: ACCEPT (k valid), REJECT, or OPEN: btrs_attempt on the same words gives the outcome.
 __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k)
 {
@@ -541,12 +584,17 @@ __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint
     k = C.ci + kf;
     const bool inr = (uint32_t)k <= (uint32_t)C.n;
     const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.2f;
+#ifdef EPI_X_NO_B_BOUNDS
+    const int bd = BTRS_OPEN;
+#else
     const int bd = btrs_bounds(C, k, btrs_lv_screen(C, v, r_us));
+#endif
     return !sure ? BTRS_OPEN : (!inr ? BTRS_REJECT : (squeeze ? BTRS_ACCEPT : bd));
 }
 #else
 // (the host pass over the kernel bodies sees a declaration; only device code calls it)
 __device__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k);
+__device__ int32_t btrs_attempt_tab(const BtrsConsts& C, double lpq, const double* __restrict__ lf_t, bool screen, uint32_t wa, uint32_t wb);
 #endif
 
 // Word pair of attempt `att` (>= 1) of a retry stream: block (att-1)/2, words (0,1) or (2,3).

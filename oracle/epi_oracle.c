@@ -83,12 +83,16 @@ static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
 static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
 
 /* ------------------------------------------------------------------ */
-/* Philox4x32-10 (Salmon et al., SC'11).  counter c[4], key k[2].      */
+/* Philox4x32 (Salmon et al., SC'11), counter c[4], key k[2].  The    */
+/* sampler streams use 7 rounds (the authors' smallest count that      */
+/* passes BigCrush); the 10-round form exists for the published        */
+/* known-answer vectors.                                               */
 /* ------------------------------------------------------------------ */
-static void philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out[4])
+#define PHILOX_ROUNDS 7
+static void philox4x32(const uint32_t c[4], const uint32_t k[2], int rounds, uint32_t out[4])
 {
     uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], k0 = k[0], k1 = k[1];
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -101,9 +105,9 @@ static void philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-void orc_philox4x32_10(const uint32_t c[4], const uint32_t k[2], uint32_t out[4])
+void orc_philox4x32(const uint32_t c[4], const uint32_t k[2], int rounds, uint32_t out[4])
 {
-    philox4x32_10(c, k, out);
+    philox4x32(c, k, rounds, out);
 }
 
 /* Stream addressing.  One Philox block is addressed by
@@ -133,7 +137,7 @@ static inline rng_t rng_make(uint64_t seed, uint64_t particle, uint32_t step)
 static inline void rng_block(const rng_t *g, uint32_t kind, uint32_t bin, uint32_t blk, uint32_t w[4])
 {
     uint32_t c[4] = { g->c0, g->c1, g->c2, (kind << 24) | (bin << 8) | blk };
-    philox4x32_10(c, g->key, w);
+    philox4x32(c, g->key, PHILOX_ROUNDS, w);
 }
 
 /* uniform in (0,1) from one word: (w + 1/2) 2^-32, exact in binary64 */

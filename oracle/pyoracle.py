@@ -48,7 +48,7 @@ def lib():
         L.orc_exp.restype = C.c_double; L.orc_exp.argtypes = [C.c_double]
         L.orc_logf.restype = C.c_float; L.orc_logf.argtypes = [C.c_float]
         L.orc_box_muller.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32)]
         L.orc_binomial.restype = C.c_int64
         L.orc_binomial.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int64, C.c_double]
         L.orc_gamma.restype = C.c_double

@@ -843,7 +843,9 @@ def test_suminf_quantiles_and_belief_summaries():
         ranks = np.clip(np.ceil(qs * n).astype(np.int64), 1, n)
         assert (got == tot[ranks - 1]).all(), (n, got, tot[ranks - 1])
     true = em.State_from((10_000.0, 5_000.0), pomdp, np.random.default_rng(0))
-    b = em.initialbelief(pomdp, 20_000, seed=SEED)
+    # (a seed whose initial belief has a mean with R >= 0: every initial particle has R = 0, so the rounded means of S and
+    # the I_i leave N - (S + sum I) = -2 ... 2, and the reference's mean asserts R >= 0, src/updater.jl:18, as the library does)
+    b = em.initialbelief(pomdp, 20_000, seed=SEED + 1)
     h = em.SimulateClosedLoop(5, true, b, pomdp, lambda bel: em.Action(0.2), seed=9, keep_beliefs="summary")
     assert len(h.beliefs) == 5
     for s in h.beliefs:

@@ -9,19 +9,24 @@ from scipy import stats
 from oracle import pyoracle
 
 
-def _philox(c, k):
+def _philox(c, k, rounds):
     L = pyoracle.lib()
     cc = (C.c_uint32 * 4)(*c); kk = (C.c_uint32 * 2)(*k); o = (C.c_uint32 * 4)()
-    L.orc_philox4x32_10(cc, kk, o)
+    L.orc_philox4x32(cc, kk, rounds, o)
     return list(o)
 
 
 def test_philox_known_answers():
-    # Random123 kat_vectors, philox4x32 with 10 rounds
-    assert _philox([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert _philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert _philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+    # Random123 kat_vectors, philox4x32 with 10 rounds (the round function) ...
+    assert _philox([0] * 4, [0] * 2, 10) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert _philox([0xffffffff] * 4, [0xffffffff] * 2, 10) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert _philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], 10) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # ... and with 7 rounds, the count the sampler streams use
+    assert _philox([0] * 4, [0] * 2, 7) == [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]
+    assert _philox([0xffffffff] * 4, [0xffffffff] * 2, 7) == [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]
+    assert _philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], 7) == \
+        [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]
 
 
 def test_log_exp_accuracy():

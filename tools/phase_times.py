@@ -18,7 +18,7 @@ pomdp = em.make_pomdp(LOD=5)
 b = em.initialbelief(pomdp, n, seed=24301)
 upd = em.BootstrapFilter(pomdp, n, seed=24301)
 L = _lib.load()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 L.epi_debug_phase_times.argtypes = [C.POINTER(C.c_ulonglong)]
 o = 400
 for step in range(6):
@@ -32,3 +32,5 @@ groups = 3 * ((n + 255) // 256)
 for k, nm in enumerate(names):
     print(f"{nm:24s} {out[k] / groups:10.0f} ticks per workgroup-step  {100.0 * out[k] / tot:5.1f} %")
 print(f"{'total':24s} {tot / groups:10.0f}")
+print(f"binomial rounds per workgroup-step {out[8] / groups:.2f}, queued draws {out[9] / groups:.1f} (round 1: {out[10] / groups:.1f}, of them rejected in the first phase {out[15] / groups:.1f}; round 2: {out[11] / groups:.1f})")
+print(f"gamma rounds per workgroup-step {out[12] / groups:.2f}, queued terms {out[13] / groups:.1f} (round 1: {out[14] / groups:.1f})")
