@@ -105,7 +105,6 @@ struct DevScalars {
     unsigned int flags;
     unsigned int pad;
 };
-static_assert(ZIG_N <= 256, "one thread per strip copies the table");
 static_assert(sizeof(DevScalars) <= 256, "the scalars of an update live in a 256-byte slot");
 
 struct epi_ctx {
@@ -482,6 +481,7 @@ __global__ __launch_bounds__(64) void k_step_one(const StepArgs A, const DevPara
 #endif
 constexpr int CTPB = EPI_CTPB;                   // threads per workgroup of the cooperative step kernel (queue entries hold 8 bits of thread index)
 constexpr unsigned int QCAP = 8 * CTPB;          // entries of the first retry queue (what the first-attempt phases leave open; rounds 2, 4, ... write it again)
+constexpr unsigned int QSEG = QCAP / (CTPB / 64); // entries of one wave's segment of the first queue
 constexpr unsigned int QCAP1 = 4 * CTPB;         // entries of the second one (what round 1, 3, ... leave open: a fraction of their input)
 static_assert(CTPB == 64 || CTPB == 128 || CTPB == 256, "whole wavefronts, 8 bits of thread index, rows padded to 256 particles");
 
@@ -565,9 +565,15 @@ __device__ unsigned long long g_phase[16];
 #ifndef EPI_X_CUT
 #define EPI_X_CUT 0
 #endif
-constexpr uint32_t COOP_BINOM_ROUNDS = 3;   // cooperative rounds of the binomial retries; what is still open after them (about one draw in
+#ifndef EPI_COOP_BINOM_ROUNDS
+#define EPI_COOP_BINOM_ROUNDS 3
+#endif
+constexpr uint32_t COOP_BINOM_ROUNDS = EPI_COOP_BINOM_ROUNDS;   // cooperative rounds of the binomial retries; what is still open after them (about one draw in
                                             // a thousand) is finished by the thread that holds it, without further barriers
-constexpr int COOP_WAVES = 4;   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
+#ifndef EPI_COOP_WAVES
+#define EPI_COOP_WAVES 4
+#endif
+constexpr int COOP_WAVES = EPI_COOP_WAVES;   // waves per SIMD the register allocation aims at (128 VGPRs): the table loads of the
                                 // binomial acceptance test want the occupancy; 3 waves (138 VGPRs, no spills) is 19 % slower
 // DELAY = false: the build for test_delay = 0 (the reference's default), without the pending-test rows and their loops.
 // HC > 0: the number of infection ages is this constant (the reference's default horizon has a build of its own).
@@ -593,7 +599,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * CTPB * 8);
     unsigned short* q1 = q0 + QCAP;
     unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP1);                 // qn[0..2]: entry counts, rotating (+ 1 pad)
-    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qn + 4);     // [CTPB/64]
+    unsigned int* qw = qn + 4;                                                     // [CTPB/64]: entries of each wave's segment of the first queue
+    unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qw + CTPB / 64);   // [CTPB/64]
     ZigEntry* ztab = reinterpret_cast<ZigEntry*>(s_max + CTPB / 64);               // [ZIG_N]: strips of the normal generator
     CoopRec* crec = reinterpret_cast<CoopRec*>(ztab + ZIG_N);                       // [2][H]: per-(draw, bin) constants for the retry rounds
 
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[tid], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
-    if (tid < ZIG_N) ztab[tid] = Dp->zig.e[tid];
+    for (int r = tid; r < ZIG_N; r += CTPB) ztab[r] = Dp->zig.e[r];
     for (int r = tid; r < 2 * H; r += CTPB) {
         const BinConsts& bc = Dp->bc[r >= H][r >= H ? r - H : r];
         crec[r] = CoopRec{bc.lpq, bc.ppx, bc.pq, bc.a0x2, bc.flip};
@@ -678,14 +685,19 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // every other draw is remembered in a bit mask (bit 2 i + j) and queued in one go after the loop: one prefix sum
     // and one LDS atomic per wave instead of one per bin.  The queued draws repeat attempt 0 in full in round 1 of
     // phase C (the words are a function of the counter: nothing has to be kept).
-    unsigned long long fm0 = 0ULL, fm1 = 0ULL, fm2 = 0ULL, fm3 = 0ULL;            // bins 0..15 / 16..31 / 32..47 / 48..63
+    // Every wave appends its open draws to a segment of its own of the first queue (wave-uniform running count, one
+    // ballot per draw: no atomics, no prefix sums); round 1 of phase C reads the segments as one list.  A draw that
+    // finds its segment full is remembered (bit 2 i + j) and finished by its thread after the loop.
+    unsigned int wcount = 0u;                                                      // entries of this wave's segment (wave-uniform)
+    unsigned long long over0 = 0ULL, over1 = 0ULL;                                 // bins 0..31 / 32..63
+    const int lane = tid & 63;
+    unsigned short* const qseg = q0 + (unsigned int)(tid >> 6) * QSEG;
 #pragma unroll 1
     for (int i = 0; i < H; i++) {
         if (active) {
             int2 nn = slots[i * CTPB + tid];
             uint32_t w[4];
             rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
-            unsigned int failbits = 0u;
             // both draws of the bin as straight code: no selects on j, and the scheduler can overlap the two
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -696,68 +708,52 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 // all of the record before the first branch: the loads go out together and are waited for once
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2));
                 int st = BTRS_ACCEPT;
-#ifdef EPI_X_SKIP_B
-                if (false) {}
-#else
                 if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
-#endif
+#ifdef EPI_X_SKIP_BDRAW
+                else if (bc.kind == 7) {
+#else
                 else if (bc.kind == 2) {
-                    if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts(n, bc.btrs()), wa, wb, x);
+#endif
+                    if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts_quick(n, bc.btrs()), wa, wb, x);
+#ifdef EPI_X_NO_INV
+                    else if (n > 0) x = 0;
+#else
                     else if (n > 0) x = binom_inversion(n, bc.lnq, bc.sr, wa);
+#endif
                 }
                 const int32_t res = st != BTRS_ACCEPT ? n : (bc.flip != 0 ? n - x : x);   // an unsettled draw keeps n for phase C
                 if (j) nn.y = res; else nn.x = res;
 #ifdef EPI_X_SKIP_C
                 st = BTRS_ACCEPT;
 #endif
-                failbits |= (unsigned int)st << (2 * j);
+                const unsigned long long mask = __ballot(st != BTRS_ACCEPT);
+                if (mask) {                                                        // wave-uniform
+                    const unsigned int pos = wcount + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
+                    if (st != BTRS_ACCEPT) {
+                        // bit 15: attempt 0 is settled (rejected), the draw goes on with attempt 1
+                        if (pos < QSEG) qseg[pos] = (unsigned short)(tid | (i << 8) | (j << 14) | ((st == BTRS_REJECT) << 15));
+                        else if (i < 32) over0 |= 1ULL << (2 * i + j);
+                        else over1 |= 1ULL << (2 * (i - 32) + j);
+                    }
+                    wcount += (unsigned int)__popcll(mask);
+                }
             }
             slots[i * CTPB + tid] = nn;
-            // four bits per bin: two per draw (1 = attempt 0 open, 2 = attempt 0 rejected)
-            if (i < 16) fm0 |= (unsigned long long)failbits << (4 * i);
-            else if (i < 32) fm1 |= (unsigned long long)failbits << (4 * (i - 16));
-            else if (i < 48) fm2 |= (unsigned long long)failbits << (4 * (i - 32));
-            else fm3 |= (unsigned long long)failbits << (4 * (i - 48));
         }
     }
-    {
-        const int lane = tid & 63;
-        // a draw is queued when either of its two bits is set
-        const unsigned long long odd = 0x5555555555555555ULL;
-        const unsigned long long q_0 = (fm0 | (fm0 >> 1)) & odd, q_1 = (fm1 | (fm1 >> 1)) & odd, q_2 = (fm2 | (fm2 >> 1)) & odd, q_3 = (fm3 | (fm3 >> 1)) & odd;
-        const unsigned int mine = (unsigned int)(__popcll(q_0) + __popcll(q_1) + __popcll(q_2) + __popcll(q_3));
-        unsigned int incl = mine;
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        const unsigned int total = __shfl(incl, 63, 64);
-        unsigned int pos = 0u;
-        if (total) {                                                                // wave-uniform
-            if (lane == 63) pos = atomicAdd(&qn[0], total);
-            pos = __shfl(pos, 63, 64) + incl - mine;
-        }
-        for (int part = 0; part < 4; part++) {
-            if (part * 16 >= H) break;
-            unsigned long long fm = part == 0 ? q_0 : (part == 1 ? q_1 : (part == 2 ? q_2 : q_3));
-            const unsigned long long both = part == 0 ? fm0 : (part == 1 ? fm1 : (part == 2 ? fm2 : fm3));
-            while (fm) {
-                const int bit = __ffsll((long long)fm) - 1;
-                fm &= fm - 1ULL;
-                const int i = (bit >> 2) + 16 * part, j = (bit >> 1) & 1;
-                const unsigned int rejected = (unsigned int)(both >> (bit + 1)) & 1u;       // attempt 0 is settled: the draw goes on with attempt 1
-                if (pos < QCAP) q0[pos] = (unsigned short)(tid | (i << 8) | (j << 14) | (rejected << 15));
-                else {                                                              // queue full: finish here
-                    const int32_t n = slot_words[(i * CTPB + tid) * 2 + j];
-                    const int32_t k = btrs_from0(n, Dp->bc[j][i].btrs(), Dp->lf, screen, g, j, (uint32_t)i);
-                    slot_words[(i * CTPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
-                }
-                pos++;
-            }
+    if (lane == 0) qw[tid >> 6] = wcount < QSEG ? wcount : QSEG;
+    for (int half = 0; half < 2; half++) {
+        unsigned long long om = half ? over1 : over0;
+        while (om) {                                                               // segment full: finish here
+            const int bit = __ffsll((long long)om) - 1;
+            om &= om - 1ULL;
+            const int i = (bit >> 1) + 32 * half, j = bit & 1;
+            const int32_t n = slot_words[(i * CTPB + tid) * 2 + j];
+            const int32_t k = btrs_from0(n, Dp->bc[j][i].btrs(), Dp->lf, screen, g, j, (uint32_t)i);
+            slot_words[(i * CTPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
         }
     }
 
-    EPI_STAMP(1);
     // ---- C: binomial rounds ----------------------------------------------------------------
     // Round r runs, in full, attempt r - 1 of the queued draws whose attempt 0 was left open and attempt r of those whose
     // attempt 0 was rejected (bit 15 of the entry).
@@ -772,7 +768,13 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         for (uint32_t round = 1; round <= COOP_BINOM_ROUNDS; round++) {
             __syncthreads();
             const unsigned int qcap_cur = (round & 1u) ? QCAP : QCAP1, qcap_next = (round & 1u) ? QCAP1 : QCAP;
-            const unsigned int cnt = qn[cur] < qcap_cur ? qn[cur] : qcap_cur;
+            // round 1: the waves' segments, end to end (up to four waves: three comparisons map a position to its segment)
+            unsigned int seg_end[CTPB / 64];
+            unsigned int cnt = 0u;
+            if (round == 1u) {
+#pragma unroll
+                for (int w = 0; w < CTPB / 64; w++) { cnt += qw[w]; seg_end[w] = cnt; }
+            } else cnt = qn[cur] < qcap_cur ? qn[cur] : qcap_cur;
             if (cnt == 0u) break;
 #ifdef EPI_PHASE_STAMPS
             if (tid == 0) { atomicAdd(&g_phase[8], 1ULL); atomicAdd(&g_phase[9], (unsigned long long)cnt); if (round == 1u) atomicAdd(&g_phase[10], (unsigned long long)cnt); if (round == 2u) atomicAdd(&g_phase[11], (unsigned long long)cnt); }
@@ -783,7 +785,14 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             unsigned short* qnext = (round & 1u) ? q1 : q0;
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
-                const unsigned short entry = q[e];
+                unsigned int at = e;
+                if (round == 1u) {
+                    unsigned int seg = 0u, first = 0u;
+#pragma unroll
+                    for (int w = 0; w + 1 < CTPB / 64; w++) if (e >= seg_end[w]) { seg = (unsigned int)w + 1u; first = seg_end[w]; }
+                    at = seg * QSEG + (e - first);
+                }
+                const unsigned short entry = q[at];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = (entry >> 14) & 1;
 #ifdef EPI_PHASE_STAMPS
                 if (round == 1u && (entry >> 15)) atomicAdd(&g_phase[15], 1ULL);
@@ -884,7 +893,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 const GammaConsts G = gamma_consts(shape, screen);
                 float xf;
                 double v;
-                const bool inside = zig_fast(wz, ztab[wz & 127u], xf);
+                const bool inside = zig_fast(wz, ztab[wz & 255u], xf);
                 // (a shape below 1 needs the boost's extra uniform: left to the rounds, which are not this loop's straight code)
                 if (gamma_fast(G, xf, wu, v) && inside && !G.boost) gslots[i * CTPB + tid] = (G.d * v) * theta_it;
                 else {
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 if (att == 0u) gamma_first(gt, (uint32_t)it, wz, wu);
                 else gamma_retry(gt, (uint32_t)it, att, wz, wu);
                 float xf;
-                if (!zig_fast(wz, ztab[wz & 127u], xf)) xf = zig_slow(&Dp->zig, gt, (att << 6) | (uint32_t)it, wz);
+                if (!zig_fast(wz, ztab[wz & 255u], xf)) xf = zig_slow(&Dp->zig, gt, (att << 6) | (uint32_t)it, wz);
                 double v;
                 const bool ok = gamma_attempt(G, xf, wu, v);
                 const bool pushed = round < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt], qcap_next);   // as above: gamma_finish_from's ending
@@ -994,7 +1003,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     EPI_STAMP(5);
 }
 
-static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + (QCAP + QCAP1) * sizeof(unsigned short) + 4 * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry) + 2 * (size_t)H * sizeof(CoopRec); }
+static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + (QCAP + QCAP1) * sizeof(unsigned short) + (4 + CTPB / 64) * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry) + 2 * (size_t)H * sizeof(CoopRec); }
 
 // launch the Philox-driven step with the selected implementation
 template <bool WEIGH>

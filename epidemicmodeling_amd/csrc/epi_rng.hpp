@@ -316,48 +316,83 @@ EPI_HD int binom_classify(int32_t n, double p, int32_t& result, double& pp, bool
     return ((double)n * pp < 10.0) ? BINOM_INVERSION : BINOM_REJECTION;
 }
 
-// 1/x for the inversion recurrence (x <= 64; beyond that a division)
-#define EPI_R(x) (1.0 / (double)(x))
+// exp(x) in binary32 for -88 < x <= 0: x = k ln 2 + r, degree-6 polynomial in r, scaled by 2^k (relative error 2e-7)
+EPI_HD float s_expf(float x)
+{
+    const float kd = __builtin_floorf(__builtin_fmaf(x, 1.44269504f, 0.5f));
+    float r = __builtin_fmaf(-kd, 6.93145752e-01f, x);
+    r = __builtin_fmaf(-kd, 1.42860677e-06f, r);
+    float p = 1.38888889e-03f;
+    p = __builtin_fmaf(p, r, 8.33333333e-03f);
+    p = __builtin_fmaf(p, r, 4.16666667e-02f);
+    p = __builtin_fmaf(p, r, 1.66666667e-01f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return u2f(f2u(p) + ((uint32_t)(int32_t)kd << 23));
+}
+
+// 1/x for the inversion recurrence (the correctly rounded quotients: a table up to 71, beyond that a division)
+#define EPI_R(x) (1.0f / (float)(x))
 #define EPI_R8(b) EPI_R(b), EPI_R(b + 1), EPI_R(b + 2), EPI_R(b + 3), EPI_R(b + 4), EPI_R(b + 5), EPI_R(b + 6), EPI_R(b + 7)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __constant__
 #else
 static
 #endif
-const double EPI_RECIP[72] = { 0.0, EPI_R(1), EPI_R(2), EPI_R(3), EPI_R(4), EPI_R(5), EPI_R(6), EPI_R(7),
+const float EPI_RECIP[72] = { 0.0f, EPI_R(1), EPI_R(2), EPI_R(3), EPI_R(4), EPI_R(5), EPI_R(6), EPI_R(7),
     EPI_R8(8), EPI_R8(16), EPI_R8(24), EPI_R8(32), EPI_R8(40), EPI_R8(48), EPI_R8(56), EPI_R8(64) };
+constexpr int EPI_RECIP_N = 72;
 
-// lnq = s_log(1 - pp), s = pp / (1 - pp): per-probability constants, tabulated per age bin by the kernels.
-// (Out of line on the device: inlined into a loop over bins, the constants of its exponential are hoisted
-// into vector registers that the loop's common path then lacks.)
-EPI_HD_OUTLINE int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
+// Sequential inversion from 0 in binary32 (n pp < 10: at most a few dozen terms matter):
+//   u = fl(w >> 8) 2^-24 + 2^-25 in (0, 1],  r_0 = exp(fl(n) lnq),  r_x = r_(x-1) (s ((fl(n) + 1 - x) (1 / x))),
+//   the result is the first x with u <= r_x after u -= r_x for the x before it, or n.
+// lnq = fl(s_log(1 - pp)), s = fl(pp / (1 - pp)): per-probability constants, tabulated per age bin by the kernels.
+// Far in the tail the terms fall below half an ulp of what is left of u and the subtraction stops making progress
+// (this happens when u exceeds the sum of the rounded terms, with probability of the order 1e-6): the search ends
+// there, at the x where r_x < u 2^-25.
+EPI_HD int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
 {
-    const double nd = (double)n;
-    const double a1 = nd + 1.0;
-    double r = s_exp(nd * lnq);
-    double u = u01(wa);
+    const float nf = (float)n, sf = (float)s;
+    const float a1 = nf + 1.0f;
+    float r = s_expf(nf * (float)lnq);
+    float u = __builtin_fmaf((float)(wa >> 8), 0x1p-24f, 0x1p-25f);
     int32_t res = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // the same recurrence with a wave-uniform counter, so that 1/x is a scalar table read
+    // the same recurrence with a wave-uniform counter, eight terms per trip: the reciprocals of a trip arrive in one
+    // wide scalar load (a load per term costs the loop its latency every time), and the wave leaves the loop at the
+    // first trip boundary after its last lane has finished
     bool live = u > r && 0 < n;
 #pragma unroll 1
-    for (int32_t x = 1; __any(live); x++) {
-        const double xd = (double)x;
-        const double t = x <= 64 ? EPI_RECIP[x] : 1.0 / xd;
-        if (live) {
-            u -= r;
-            res = x;
-            r *= s * ((a1 - xd) * t);
-            live = u > r && x < n;
+    for (int32_t xb = 1; __any(live); xb += 8) {
+        float t8[8];
+        if (xb + 7 < EPI_RECIP_N) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) t8[k] = EPI_RECIP[xb + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) t8[k] = div_rn(1.0f, (float)(xb + k));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int32_t x = xb + k;
+            const float xf = (float)x;
+            if (live) {
+                u -= r;
+                res = x;
+                r *= sf * ((a1 - xf) * t8[k]);
+                live = u > r && x < n && !(r < u * 0x1p-25f);
+            }
         }
     }
 #else
     while (u > r && res < n) {
         u -= r;
         res += 1;
-        const double xd = (double)res;
-        const double t = res <= 64 ? EPI_RECIP[res] : 1.0 / xd;
-        r *= s * ((a1 - xd) * t);
+        const float xf = (float)res;
+        const float t = 1.0f / xf;
+        r *= sf * ((a1 - xf) * t);
+        if (r < u * 0x1p-25f) break;
     }
 #endif
     return res;
@@ -575,7 +610,27 @@ __device__ __forceinline__ int32_t btrs_attempt_tab(const BtrsConsts& C, double 
 #endif
 
 #if defined(EPI_HAVE_SCREEN)
+// The per-draw constants for btrs_quick only: the square root is the hardware's (good to one ulp, where btrs_consts
+// takes the correctly rounded one), so b, 2a and everything derived from them may differ from the defining values by a
+// few parts in 10^7.  btrs_quick's decisions all carry bands that cover this.
+__device__ __forceinline__ BtrsConsts btrs_consts_quick(int32_t n, const BtrsBin& B)
+{
+    BtrsConsts C;
+    C.n = n;
+    C.npq = (float)n * B.pq;
+    C.spq = __builtin_amdgcn_sqrtf(C.npq);
+    C.b = __builtin_fmaf(2.53f, C.spq, 1.15f);
+    C.a2 = __builtin_fmaf(0.0496f, C.b, B.a0x2);
+    const uint64_t prod = (uint64_t)(uint32_t)n * B.ppx + 0x80000000ULL;
+    C.ci = (int32_t)(uint32_t)(prod >> 32);
+    C.cfr = u2f(0x3f800000u | ((uint32_t)prod >> 9)) - 1.0f;
+    C.m = (int32_t)(uint32_t)(((uint64_t)((uint32_t)n + 1u) * B.ppx) >> 32);
+    return C;
+}
+
 // An attempt without the table: ACCEPT (k valid), REJECT, or OPEN: btrs_attempt on the same words gives the outcome.
+// (C from btrs_consts_quick.  The squeeze is claimed only with a margin of 1e-6 on its threshold; the candidate's band
+// and the bands of the bounds are wide enough for the constants' few parts in 10^7 as they stand.)
 __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k)
 {
     const float u = btrs_u(wa), us = btrs_us(u), v = btrs_v(wb);
@@ -583,7 +638,7 @@ __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint
     const bool sure = btrs_kfloor_screen(C, u, us, r_us, kf);
     k = C.ci + kf;
     const bool inr = (uint32_t)k <= (uint32_t)C.n;
-    const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.2f;
+    const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.200005f;
 #ifdef EPI_X_NO_B_BOUNDS
     const int bd = BTRS_OPEN;
 #else
@@ -594,6 +649,7 @@ __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint
 #else
 // (the host pass over the kernel bodies sees a declaration; only device code calls it)
 __device__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k);
+__device__ BtrsConsts btrs_consts_quick(int32_t n, const BtrsBin& B);
 __device__ int32_t btrs_attempt_tab(const BtrsConsts& C, double lpq, const double* __restrict__ lf_t, bool screen, uint32_t wa, uint32_t wb);
 #endif
 
@@ -640,31 +696,31 @@ EPI_HD int32_t binomial_draw(int32_t n, double p, uint32_t fa, uint32_t fb,
     return flip ? n - x : x;
 }
 
-// ---- standard normal: ziggurat (Marsaglia & Tsang 2000), 128 strips of equal area ----------------------------
-// Strip k = 1..127 is the rectangle [0, x_k] x [f(x_k), f(x_{k+1})], f(x) = exp(-x^2 / 2), x_1 = r > x_2 > ... >
-// x_128 = 0; strip 0 is [0, r] x [0, f(r)] plus the tail beyond r, with nominal width X_0 = area / f(r).  One 32-bit
-// word gives the strip (bits 0-6), the sign (bit 7) and a 24-bit position j: x = fl(j) wn[k], wn[k] = X_k 2^-24.
+// ---- standard normal: ziggurat (Marsaglia & Tsang 2000), 256 strips of equal area ----------------------------
+// Strip k = 1..255 is the rectangle [0, x_k] x [f(x_k), f(x_{k+1})], f(x) = exp(-x^2 / 2), x_1 = r > x_2 > ... >
+// x_256 = 0; strip 0 is [0, r] x [0, f(r)] plus the tail beyond r, with nominal width X_0 = area / f(r).  One 32-bit
+// word gives the strip (bits 0-7), the sign (bit 8) and a 23-bit position j: x = fl(j) wn[k], wn[k] = X_k 2^-23.
 // j < kn[k] (x inside the part of the strip that lies wholly under the curve): x is returned.  That is all the
-// fast path does: one 8-byte table entry, a conversion, a multiplication and a comparison, for 98.8 % of the words.
+// fast path does: one 8-byte table entry, a conversion, a multiplication and a comparison, for 98.9 % of the words.
 // Otherwise (zig_slow): a wedge point is accepted iff f(x_k) + U (f(x_{k+1}) - f(x_k)) < f(x); the tail is
 // Marsaglia's: x = -log(U1) / r, accepted iff -2 log(U2) > x^2, giving r + x; a rejected wedge point starts over
 // with a fresh word, a rejected tail point repeats the tail step.  Step l of this takes Philox block l of the
 // stream (K_ZIG, attempt << 6 | term): words 0, 1 -> U, U1 / U2 (32-bit binary64 uniforms), word 2 -> the next
 // candidate word.  The slow path is binary64 throughout (s_exp, s_log as above).
-constexpr int ZIG_N = 128;
+constexpr int ZIG_N = 256;
 constexpr uint32_t K_ZIG = 8u;
 constexpr uint32_t ZIG_MAX_STEPS = 64u;
 struct ZigEntry { uint32_t kn; float wn; };
 struct ZigTable {
     ZigEntry e[ZIG_N];
-    double fn[ZIG_N + 1];        // f(x_k), k = 1..128 (fn[0] unused)
+    double fn[ZIG_N + 1];        // f(x_k), k = 1..256 (fn[0] unused)
     double r;
 };
 
-// (host) the table, from the strip area and r of the published 128-strip construction
+// (host) the table, from the strip area and r of the published 256-strip construction
 inline void zig_build(ZigTable& T)
 {
-    const double r = 3.442619855899, v = 9.91256303526217e-3;
+    const double r = 3.6541528853610088, v = 4.92867323399e-3;
     double x[ZIG_N + 1];
     x[1] = r;
     for (int k = 1; k < ZIG_N - 1; k++) x[k + 1] = __builtin_sqrt(-2.0 * s_log(v / x[k] + s_exp(-0.5 * x[k] * x[k])));
@@ -675,7 +731,7 @@ inline void zig_build(ZigTable& T)
     for (int k = 0; k < ZIG_N; k++) {
         const double X = k == 0 ? v / T.fn[1] : x[k];
         const double inner = x[k + 1];                       // k = 0: r
-        T.e[k].wn = (float)(X * 0x1p-24);
+        T.e[k].wn = (float)(X * 0x1p-23);
         // every position below kn lies under the curve whatever the rounding of wn and of the product
         T.e[k].kn = (uint32_t)((inner / (double)T.e[k].wn) * (1.0 - 0x1p-22));
     }
@@ -683,9 +739,9 @@ inline void zig_build(ZigTable& T)
 
 EPI_HD bool zig_fast(uint32_t w, const ZigEntry e, float& x)
 {
-    const uint32_t j = w >> 8;
+    const uint32_t j = w >> 9;
     const float xa = (float)j * e.wn;
-    x = u2f(f2u(xa) | ((w & 128u) << 24));
+    x = u2f(f2u(xa) | ((w & 256u) << 23));
     return j < e.kn;
 }
 
@@ -700,8 +756,8 @@ EPI_HD_OUTLINE float zig_slow(const ZigTable* __restrict__ T, const Rng g, uint3
         uint32_t q[4];
         rng_block(g, K_ZIG, term_att, l, q);
         if (!tail) {
-            const uint32_t k = w & 127u, j = w >> 8;
-            sign = (w & 128u) << 24;
+            const uint32_t k = w & 255u, j = w >> 9;
+            sign = (w & 256u) << 23;
             x = (float)j * T->e[k].wn;
             if (j < T->e[k].kn) break;
             if (k == 0u) tail = true;
@@ -722,7 +778,7 @@ EPI_HD_OUTLINE float zig_slow(const ZigTable* __restrict__ T, const Rng g, uint3
 EPI_HD float zig_normal(const ZigTable* __restrict__ T, const Rng& g, uint32_t term_att, uint32_t w)
 {
     float x;
-    if (zig_fast(w, T->e[w & 127u], x)) return x;
+    if (zig_fast(w, T->e[w & 255u], x)) return x;
     return zig_slow(T, g, term_att, w);
 }
 

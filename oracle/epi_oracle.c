@@ -289,11 +289,29 @@ static void binom_pair(binom_src *s, uint32_t attempt, uint32_t *wa, uint32_t *w
 
 #define BINOM_MAX_ATTEMPTS 512u
 
-static double recip_tab[65];
+static float recip_tab[65];
 __attribute__((constructor)) static void recip_init(void)
 {
-    for (int x = 1; x <= 64; x++) recip_tab[x] = 1.0 / (double)x;
+    for (int x = 1; x <= 64; x++) recip_tab[x] = 1.0f / (float)x;
 }
+
+/* exp(x) in binary32, -88 < x <= 0 */
+static float s_expf(float x)
+{
+    float kd = floorf(fmaf(x, 1.44269504f, 0.5f));
+    float r = fmaf(-kd, 6.93145752e-01f, x);
+    r = fmaf(-kd, 1.42860677e-06f, r);
+    float p = 1.38888889e-03f;
+    p = fmaf(p, r, 8.33333333e-03f);
+    p = fmaf(p, r, 4.16666667e-02f);
+    p = fmaf(p, r, 1.66666667e-01f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return u2f(f2u(p) + ((uint32_t)(int32_t)kd << 23));
+}
+
+float orc_expf(float x) { return s_expf(x); }
 
 static int64_t binomial_draw(int64_t n, double p, binom_src *src)
 {
@@ -307,18 +325,20 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
     if (nd * pp < 10.0) {
         uint32_t wa, wb;
         binom_pair(src, 0, &wa, &wb);
-        /* sequential inversion: pmf(x) = pmf(x-1) s (n+1-x)/x, with 1/x tabulated up to 64 */
-        double s = pp / qq;
-        double a1 = nd + 1.0;
-        double r = s_exp(nd * s_log(qq));
-        double u = u01(wa);
+        /* sequential inversion in binary32: pmf(x) = pmf(x-1) s (n+1-x)/x, with 1/x tabulated up to 64; the search
+         * also ends where the terms have fallen below half an ulp of what is left of u (no progress possible) */
+        float nf = (float)(int32_t)n, sf = (float)(pp / qq);
+        float a1 = nf + 1.0f;
+        float r = s_expf(nf * (float)s_log(qq));
+        float u = fmaf((float)(wa >> 8), 0x1p-24f, 0x1p-25f);
         x = 0;
         while (u > r && x < n) {
             u -= r;
             x += 1;
-            double xd = (double)x;
-            double t = x <= 64 ? recip_tab[x] : 1.0 / xd;
-            r *= s * ((a1 - xd) * t);
+            float xf = (float)(int32_t)x;
+            float t = x <= 64 ? recip_tab[x] : 1.0f / xf;
+            r *= sf * ((a1 - xf) * t);
+            if (r < u * 0x1p-25f) break;
         }
     } else {
         /* Hat in binary32 (Hoermann's constants carry 3 digits); the centre c = n pp + 1/2 and the mode
@@ -368,16 +388,16 @@ static int64_t binomial_draw(int64_t n, double p, binom_src *src)
 #define GAMMA_MAX_ATTEMPTS 512u
 #define GAMMA_MIN_SHAPE 0x1p-30
 
-/* Standard normal by the ziggurat of Marsaglia & Tsang (2000) with 128 strips of equal area v: strip k >= 1 is
- * [0, x_k] x [f(x_k), f(x_{k+1})], x_1 = r, x_128 = 0, f(x) = exp(-x^2/2); strip 0 is the base [0, r] x [0, f(r)]
- * plus the tail, nominal width v / f(r).  A 32-bit word gives strip (bits 0-6), sign (bit 7), position j (24 bits). */
-#define ZIG_N 128
+/* Standard normal by the ziggurat of Marsaglia & Tsang (2000) with 256 strips of equal area v: strip k >= 1 is
+ * [0, x_k] x [f(x_k), f(x_{k+1})], x_1 = r, x_256 = 0, f(x) = exp(-x^2/2); strip 0 is the base [0, r] x [0, f(r)]
+ * plus the tail, nominal width v / f(r).  A 32-bit word gives strip (bits 0-7), sign (bit 8), position j (23 bits). */
+#define ZIG_N 256
 #define K_ZIG 8u
 #define ZIG_MAX_STEPS 64u
 static uint32_t zig_kn[ZIG_N];
 static float zig_wn[ZIG_N];
 static double zig_fn[ZIG_N + 1];
-static const double zig_r = 3.442619855899, zig_v = 9.91256303526217e-3;
+static const double zig_r = 3.6541528853610088, zig_v = 4.92867323399e-3;
 
 __attribute__((constructor)) static void zig_init(void)
 {
@@ -389,7 +409,7 @@ __attribute__((constructor)) static void zig_init(void)
     for (int k = 1; k <= ZIG_N; k++) zig_fn[k] = k == ZIG_N ? 1.0 : s_exp(-0.5 * x[k] * x[k]);
     for (int k = 0; k < ZIG_N; k++) {
         double X = k == 0 ? zig_v / zig_fn[1] : x[k];
-        zig_wn[k] = (float)(X * 0x1p-24);
+        zig_wn[k] = (float)(X * 0x1p-23);
         zig_kn[k] = (uint32_t)((x[k + 1] / (double)zig_wn[k]) * (1.0 - 0x1p-22));
     }
 }
@@ -408,8 +428,8 @@ static float zig_normal(const rng_t *g, uint32_t term, uint32_t att, uint32_t w)
     float x = 0.f;
     for (uint32_t l = 0; l < ZIG_MAX_STEPS; l++) {
         if (!tail) {
-            uint32_t k = w & 127u, j = w >> 8;
-            sign = (w & 128u) << 24;
+            uint32_t k = w & 255u, j = w >> 9;
+            sign = (w & 256u) << 23;
             x = (float)j * zig_wn[k];
             if (j < zig_kn[k]) break;                      /* inside the strip's rectangle under the curve */
             if (k == 0) tail = 1;
