@@ -706,7 +706,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 int32_t x = 0;
                 const BinConsts bc = Dp->bc[j][i];                                 // wave-uniform: scalar loads
                 // all of the record before the first branch: the loads go out together and are waited for once
-                asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2));
+                asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2), "s"(bc.ppf), "s"(bc.hqp), "s"(bc.c3u), "s"(bc.c3d));
                 int st = BTRS_ACCEPT;
                 if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
 #ifdef EPI_X_SKIP_BDRAW
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 #else
                 else if (bc.kind == 2) {
 #endif
-                    if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts_quick(n, bc.btrs()), wa, wb, x);
+                    if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts_quick(n, bc.btrs()), bc.side(), wa, wb, x);
 #ifdef EPI_X_NO_INV
                     else if (n > 0) x = 0;
 #else
@@ -3125,6 +3125,54 @@ __global__ __launch_bounds__(256) void k_f32_forms(int mode, uint32_t first_bits
         bad += f2u(got) != f2u(want);
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+// The table-free attempt (btrs_quick) against the defining one on random (n, words): out[0] attempts, out[1] settled as
+// accepted, out[2] settled as rejected, out[3] left open, out[4] settled differently from the defining test (must be 0).
+__global__ __launch_bounds__(256) void k_btrs_quick_check(uint64_t seed, int32_t n_lo, uint32_t n_span, double pp, LfTable lf, unsigned long long* out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const Rng g = rng_make(seed, (uint64_t)i, 0);
+    uint32_t h[4];
+    rng_block(g, 9, 0, 0, h);
+    const int32_t n = n_lo + (int32_t)(h[0] % n_span);
+    unsigned long long cnt[5] = {0, 0, 0, 0, 0};
+    if ((double)n * pp >= 10.0) {
+        const BtrsBin B = btrs_bin(pp);
+        const BtrsSide S = btrs_side(pp);
+        const BtrsConsts Cq = btrs_consts_quick(n, B), C = btrs_consts(n, B);
+        for (uint32_t r = 0; r < 32; r++) {
+            uint32_t w[4];
+            rng_block(g, 1, r, 0, w);
+            for (int half = 0; half < 2; half++) {
+                int32_t kq;
+                const int st = btrs_quick(Cq, S, w[2 * half], w[2 * half + 1], kq);
+                const int32_t kd = btrs_attempt(C, B.lpq, lf, false, w[2 * half], w[2 * half + 1]);
+                cnt[0]++;
+                cnt[1] += st == BTRS_ACCEPT; cnt[2] += st == BTRS_REJECT; cnt[3] += st == BTRS_OPEN;
+                cnt[4] += (st == BTRS_ACCEPT && kd != kq) || (st == BTRS_REJECT && kd >= 0);
+            }
+        }
+    }
+    for (int q = 0; q < 5; q++) {
+        unsigned long long v = cnt[q];
+        for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[q], v);
+    }
+}
+
+int epi_debug_btrs_quick(epi_ctx* c, uint64_t seed, int32_t n_lo, uint32_t n_span, double pp, int blocks, uint64_t* out5)
+{
+    if (!c || !out5 || n_lo < 1 || n_span < 1 || !(pp > 0.0 && pp <= 0.5) || blocks < 1) return fail(EPI_EINVAL, "epi_debug_btrs_quick: bad argument");
+    HIPCHECK(hipSetDevice(c->device));
+    DevBuf d;
+    if (d.alloc(5 * sizeof(unsigned long long)) != hipSuccess) return fail(EPI_ENOMEM, "epi_debug_btrs_quick: hipMalloc failed");
+    HIPCHECK(hipMemsetAsync(d.p, 0, 5 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_btrs_quick_check, dim3((unsigned)blocks), dim3(256), 0, c->stream, seed, n_lo, n_span, pp, LfTable{c->d_lf, LF_TABLE_N}, (unsigned long long*)d.p);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out5, d.p, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return EPI_OK;
 }
 
 int epi_debug_f32_forms(epi_ctx* c, int mode, float first, float last, uint64_t* mismatches)

@@ -435,9 +435,27 @@ EPI_HD BtrsBin btrs_bin(double pp)
     return B;
 }
 
+// constants of the table-free bounds of the acceptance test (btrs_bounds), per probability
+struct BtrsSide {
+    float ppf;          // pp
+    float hqp;          // (1 - 2 pp) / 2
+    float c3u, c3d;     // (2 P^3 + Q^3) / 3 for (P, Q) = (pp, 1 - pp) above the mode and (1 - pp, pp) below it, rounded up
+};
+EPI_HD BtrsSide btrs_side(double pp)
+{
+    const double qq = 1.0 - pp;
+    BtrsSide S;
+    S.ppf = (float)pp;
+    S.hqp = (float)(0.5 * (qq - pp));
+    S.c3u = (float)((2.0 * pp * pp * pp + qq * qq * qq) / 3.0 * 1.000001);
+    S.c3d = (float)((2.0 * qq * qq * qq + pp * pp * pp) / 3.0 * 1.000001);
+    return S;
+}
+
 struct BtrsConsts {
     float npq, spq, b, a2, cfr;
     int32_t ci, m, n;
+    float hf, rV;       // btrs_consts_quick only: 1/2 - frac((n + 1) pp) and 1 / ((n + 1) pp (1 - pp))
 };
 
 EPI_HD BtrsConsts btrs_consts(int32_t n, const BtrsBin& B)
@@ -515,23 +533,39 @@ __device__ __forceinline__ float btrs_lv_screen(const BtrsConsts& C, float v, fl
 
 enum { BTRS_ACCEPT = 0, BTRS_OPEN = 1, BTRS_REJECT = 2 };
 #ifdef EPI_HAVE_SCREEN
-// Bounds on the right side of the acceptance test that need no table (Kachitvichyanukul & Schmeiser 1988, the squeeze
-// of algorithm BTPE): for j = |k - m| < n p q / 2 - 1,  | log f(k) - log f(m) + j^2 / (2 n p q) | <= rho(j),
-//   rho(j) = (j / npq) ((j (j / 3 + 0.625) + 1/6) / npq + 1/2).
-// The estimate lvf of the left side decides when it clears a bound by more than the errors of both sides (its own
-// band as below; t and rho carry a hardware reciprocal and five roundings): ACCEPT / REJECT are then the outcome of
-// the defining test, OPEN leaves it to that test.
-__device__ __forceinline__ int btrs_bounds(const BtrsConsts& C, int32_t k, float lvf)
+// Bounds on the right side of the acceptance test, L = log f(k) - log f(m), that need no table.  With x* = (n + 1) pp,
+// m = floor(x*), F = x* - m and V = (n + 1) pp (1 - pp), the ratio of neighbouring probabilities is
+//   f(m + i) / f(m + i - 1) = (V - s P) / (V + s Q),  s = i - F, (P, Q) = (pp, 1 - pp)                 above the mode,
+//   f(m - i) / f(m - i + 1) = (V - s P) / (V + s Q),  s = i - (1 - F), (P, Q) = (1 - pp, pp)          below it,
+// so that for j = |k - m|, from log(1 - a) <= -a - a^2/2, log(1 + b) >= b - b^2/2 and the cubic remainders of the two series,
+//   U0 - R <= L <= U0,   U0 = -S1 / V + (Q - P) S2 / (2 V^2),   R = (P^3 / (1 - j P / V) + Q^3) S3 / (3 V^3),
+//   S1 = sum s = j ((j + 1)/2 - F'),  S2 = sum s^2,  S3 = sum s^3 <= (j (j + 1) / 2)^2          (F' = F or 1 - F).
+// Here S2 is taken as j^2 (j/3 + 1/2 - F'), which leaves out a term of at most j/6: e2 = 0.084 j / V^2 on either side;
+// j P / V < 1/2 is required (R then uses 2 P^3 + Q^3).  At j = 2 sigma the band R is about 1 / sigma^2: a few draws in
+// a thousand stay undecided, where the classical bounds of this kind (BTPE's squeeze, band ~ 1 / sigma) leave one in eight.
+// The estimate lvf of the left side decides when it clears a bound by more than the errors of both sides: its own band,
+// 2e-6 |U0| for the hardware reciprocal and the roundings, and j / V times the uncertainty of F (pp in 0.32 fixed
+// point times n, plus the 23 bits kept).  ACCEPT / REJECT are then the outcome of the defining test; OPEN leaves it to that test.
+__device__ __forceinline__ int btrs_bounds(const BtrsConsts& C, const BtrsSide& S, int32_t k, float lvf)
 {
     const int32_t d = k - C.m;
-    const float j = (float)(d < 0 ? -d : d);
-    const float rn = f_rcp(C.npq);
-    const float x1 = j * rn;
-    const float t = -0.5f * j * x1;
-    const float rho = x1 * __builtin_fmaf(__builtin_fmaf(j, __builtin_fmaf(j, 0.33333334f, 0.625f), 0.16666667f), rn, 0.5f);
-    const float g = __builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, __builtin_fmaf(rho - t, 2e-6f, BTRS_GUARD_ABS));
-    const bool valid = j < __builtin_fmaf(0.5f, C.npq, -1.0f);
-    const bool acc = lvf + g <= t - rho, rej = lvf - g > t + rho;
+    const bool below = d < 0;
+    const float j = (float)(below ? -d : d);
+    const float hF = below ? -C.hf : C.hf;                       // 1/2 - F'
+    const float cq = below ? -S.hqp : S.hqp;                     // (Q - P) / 2
+    const float c3 = below ? S.c3d : S.c3u;
+    const float P = below ? 1.0f - S.ppf : S.ppf;
+    const float rV = C.rV, rV2 = rV * rV;
+    const float S1 = j * __builtin_fmaf(0.5f, j, hF);
+    const float S2 = (j * j) * __builtin_fmaf(0.33333334f, j, hF);
+    const float U0 = -rV * __builtin_fmaf(-(cq * rV), S2, S1);
+    const float jp1 = j + 1.0f, q2 = jp1 * jp1;
+    const float e2 = (0.084f * j) * rV2;
+    const float R = __builtin_fmaf((c3 * (0.25f * q2 * q2)) * rV2, rV, e2);
+    const float gf = (j * rV) * __builtin_fmaf((float)C.n, 1.2e-10f, 2e-7f);
+    const float g = __builtin_fmaf(__builtin_fabsf(lvf), BTRS_GUARD_REL, __builtin_fmaf(__builtin_fabsf(U0), 2e-6f, BTRS_GUARD_ABS + gf)) + e2;
+    const bool valid = (j * P) * rV < 0.5f;
+    const bool acc = lvf + g <= U0 - R, rej = lvf - g > U0;
     return !valid ? BTRS_OPEN : (acc ? BTRS_ACCEPT : (rej ? BTRS_REJECT : BTRS_OPEN));
 }
 #endif
@@ -554,11 +588,7 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, 
     if (us >= 0.07f && (0.92f - v) * C.b >= 4.2f) return k;
 #ifdef EPI_HAVE_SCREEN
     float lvf = 0.f;
-    if (screen) {
-        lvf = btrs_lv_screen(C, v, r_us);
-        const int bd = btrs_bounds(C, k, lvf);
-        if (bd != BTRS_OPEN) return bd == BTRS_ACCEPT ? k : -1;
-    }
+    if (screen) lvf = btrs_lv_screen(C, v, r_us);
 #endif
 #ifdef EPI_X_NO_TABLE
     return k;
@@ -624,14 +654,17 @@ __device__ __forceinline__ BtrsConsts btrs_consts_quick(int32_t n, const BtrsBin
     const uint64_t prod = (uint64_t)(uint32_t)n * B.ppx + 0x80000000ULL;
     C.ci = (int32_t)(uint32_t)(prod >> 32);
     C.cfr = u2f(0x3f800000u | ((uint32_t)prod >> 9)) - 1.0f;
-    C.m = (int32_t)(uint32_t)(((uint64_t)((uint32_t)n + 1u) * B.ppx) >> 32);
+    const uint64_t pm = (uint64_t)((uint32_t)n + 1u) * B.ppx;
+    C.m = (int32_t)(uint32_t)(pm >> 32);
+    C.hf = 1.5f - u2f(0x3f800000u | ((uint32_t)pm >> 9));       // 1/2 - frac((n + 1) pp), the fraction to 23 bits
+    C.rV = f_rcp(C.npq + B.pq);
     return C;
 }
 
 // An attempt without the table: ACCEPT (k valid), REJECT, or OPEN: btrs_attempt on the same words gives the outcome.
 // (C from btrs_consts_quick.  The squeeze is claimed only with a margin of 1e-6 on its threshold; the candidate's band
 // and the bands of the bounds are wide enough for the constants' few parts in 10^7 as they stand.)
-__device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k)
+__device__ __forceinline__ int btrs_quick(const BtrsConsts& C, const BtrsSide& S, uint32_t wa, uint32_t wb, int32_t& k)
 {
     const float u = btrs_u(wa), us = btrs_us(u), v = btrs_v(wb);
     float r_us; int32_t kf;
@@ -642,13 +675,13 @@ __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint
 #ifdef EPI_X_NO_B_BOUNDS
     const int bd = BTRS_OPEN;
 #else
-    const int bd = btrs_bounds(C, k, btrs_lv_screen(C, v, r_us));
+    const int bd = btrs_bounds(C, S, k, btrs_lv_screen(C, v, r_us));
 #endif
     return !sure ? BTRS_OPEN : (!inr ? BTRS_REJECT : (squeeze ? BTRS_ACCEPT : bd));
 }
 #else
 // (the host pass over the kernel bodies sees a declaration; only device code calls it)
-__device__ int btrs_quick(const BtrsConsts& C, uint32_t wa, uint32_t wb, int32_t& k);
+__device__ int btrs_quick(const BtrsConsts& C, const BtrsSide& S, uint32_t wa, uint32_t wb, int32_t& k);
 __device__ BtrsConsts btrs_consts_quick(int32_t n, const BtrsBin& B);
 __device__ int32_t btrs_attempt_tab(const BtrsConsts& C, double lpq, const double* __restrict__ lf_t, bool screen, uint32_t wa, uint32_t wb);
 #endif

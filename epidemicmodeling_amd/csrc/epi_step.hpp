@@ -39,13 +39,15 @@ __host__ __device__ __forceinline__ int tests_row(int H, int r0, int c0) { retur
 // Everything one binomial draw of one age bin reads from the parameters, in one 64-byte record: the kernels fetch it
 // with a single wide scalar load (one wait) instead of a chain of dependent loads from the separate tables below.
 struct alignas(64) BinConsts {
-    double lpq, lnq, sr;        // as in the tables below
-    const double* lf_t;         // the log-factorial table (same for every bin)
+    double lpq;                 // s_log(pp / (1 - pp))
+    double lnq, sr;             // the inversion sampler's constants (as in the tables below)
     uint32_t ppx;               // the rejection sampler's per-probability constants (btrs_bin)
     float pq, a0x2;
     uint32_t nthr;
-    int32_t kind, flip, lf_n;
+    int32_t kind, flip;
+    float ppf, hqp, c3u, c3d;   // for the table-free bounds of the acceptance test (btrs_side)
     __host__ __device__ __forceinline__ BtrsBin btrs() const { return BtrsBin{ppx, pq, a0x2, lpq}; }
+    __host__ __device__ __forceinline__ BtrsSide side() const { return BtrsSide{ppf, hqp, c3u, c3d}; }
 };
 static_assert(sizeof(BinConsts) == 64, "one 64-byte record per (draw, bin)");
 
@@ -74,7 +76,8 @@ inline void pack_bin_consts(DevParams& D)
             const BtrsBin B = btrs_bin(D.pp[j][i]);
             b.lpq = B.lpq; b.lnq = D.lnq[j][i]; b.sr = D.sr[j][i];
             b.ppx = B.ppx; b.pq = B.pq; b.a0x2 = B.a0x2;
-            b.lf_t = D.lf.t; b.lf_n = D.lf.n;
+            const BtrsSide S = btrs_side(D.pp[j][i]);
+            b.ppf = S.ppf; b.hqp = S.hqp; b.c3u = S.c3u; b.c3d = S.c3d;
             b.nthr = D.nthr[j][i]; b.kind = D.kind[j][i]; b.flip = D.flip[j][i];
         }
 }

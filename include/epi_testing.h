@@ -30,6 +30,13 @@ int epi_debug_f32_forms(epi_ctx *ctx, int mode, float first, float last, uint64_
  * leaves four workgroups per CU), 2 forces the cooperative kernel, 0 the per-thread one.  Testing aid,
  * process-wide. */
 int epi_debug_step_impl(int cooperative);
+/* The cooperative step kernel settles most binomial rejection draws in its first phase without the log-factorial
+ * table (squeeze, and bounds on log f(k) - log f(m) from the series of the ratio of neighbouring probabilities); what
+ * it settles must be what the defining acceptance test gives.  This runs blocks * 256 threads, each 64 attempts at a
+ * random n in [n_lo, n_lo + n_span) and the folded probability pp, through both and returns in out5: attempts, settled
+ * as accepted, settled as rejected, left open, settled differently from the defining test (must be 0).  No counterpart
+ * in the reference. */
+int epi_debug_btrs_quick(epi_ctx *ctx, uint64_t seed, int32_t n_lo, uint32_t n_span, double pp, int blocks, uint64_t *out5);
 
 #ifdef __cplusplus
 }

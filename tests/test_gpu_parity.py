@@ -708,6 +708,28 @@ def test_step_implementations_and_screens_agree(delay, testing_lib):
         check(lib.epi_debug_screen(1))
 
 
+def test_table_free_binomial_attempt_agrees_with_the_defining_test(testing_lib):
+    """What the first phase of the cooperative kernel settles without the log-factorial table (squeeze, series bounds
+    on log f(k) - log f(m)) is what the defining acceptance test gives: 2.7e7 attempts per case, from the smallest
+    n p the rejection sampler takes to populations of 10^9, small and large standard deviations; and the bounds
+    leave few attempts open where the standard deviation is not tiny."""
+    ctx = em.interface.context_for(em.make_pomdp(LOD=5))
+    out = (C.c_uint64 * 5)()
+    cases = [(20, 40, 0.5), (25, 200, 0.4), (100, 2000, 0.3), (2000, 20000, 0.0051), (2000, 20000, 0.035), (2000, 20000, 0.127),
+             (1000, 3000, 0.245), (500, 4000, 0.4401), (5000, 20000, 0.0025), (100000, 900000, 0.0001), (100000, 900000, 0.5),
+             (1000000, 15000000, 0.003), (1000000, 15000000, 0.49), (4000000, 12000000, 0.000003), (1 << 30, 1 << 30, 0.37),
+             (1 << 30, 1 << 30, 1.1e-8)]
+    for k, (lo, span, pp) in enumerate(cases):
+        check(ctx.lib.epi_debug_btrs_quick(ctx.handle, 1000 + k, lo, span, pp, 1650, out))
+        tot, acc, rej, opn, bad = (int(v) for v in out)
+        assert tot > 1e7 and acc + rej + opn == tot, (lo, span, pp, list(out))
+        assert bad == 0, (lo, span, pp, list(out))
+        assert acc > 0.7 * tot
+        sigma = np.sqrt((lo + span / 2) * pp * (1 - pp))
+        if sigma >= 8 and lo < 1 << 24:                    # (beyond 2^24 the binary32 arithmetic of the bounds is what leaves attempts open)
+            assert opn < 0.02 * tot, (lo, span, pp, sigma, opn / tot)
+
+
 def test_short_binary32_sqrt_and_quotient_are_correctly_rounded(testing_lib):
     """The device forms of the binary32 square root and quotient used by the samplers against
     the compiler's general expansions (what the host oracle's sqrtf and "/" compute), on EVERY
