@@ -570,6 +570,10 @@ __device__ unsigned long long g_phase[16];
 #endif
 constexpr uint32_t COOP_BINOM_ROUNDS = EPI_COOP_BINOM_ROUNDS;   // cooperative rounds of the binomial retries; what is still open after them (about one draw in
                                             // a thousand) is finished by the thread that holds it, without further barriers
+#ifndef EPI_COOP_GAMMA_ROUNDS
+#define EPI_COOP_GAMMA_ROUNDS 1
+#endif
+constexpr uint32_t COOP_GAMMA_ROUNDS = EPI_COOP_GAMMA_ROUNDS;   // the same for the infection terms (a term in a thousand is open after one round)
 #ifndef EPI_COOP_WAVES
 #define EPI_COOP_WAVES 4
 #endif
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     {
         int cur = 0;
 #pragma unroll 1
-        for (uint32_t round = 1; round <= GAMMA_MAX_ATTEMPTS; round++) {
+        for (uint32_t round = 1; round <= COOP_GAMMA_ROUNDS; round++) {
             __syncthreads();
             const unsigned int qcap_cur = (round & 1u) ? QCAP : QCAP1, qcap_next = (round & 1u) ? QCAP1 : QCAP;
             const unsigned int cnt = qn[cur] < qcap_cur ? qn[cur] : qcap_cur;
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 if (!zig_fast(wz, ztab[wz & 255u], xf)) xf = zig_slow(&Dp->zig, gt, (att << 6) | (uint32_t)it, wz);
                 double v;
                 const bool ok = gamma_attempt(G, xf, wu, v);
-                const bool pushed = round < GAMMA_MAX_ATTEMPTS && q_push(!ok, entry, qnext, &qn[nxt], qcap_next);   // as above: gamma_finish_from's ending
+                const bool pushed = round < COOP_GAMMA_ROUNDS && q_push(!ok, entry, qnext, &qn[nxt], qcap_next);   // after the cooperative rounds: finished by this thread
                 if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
                 else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], &Dp->zig, gt, (uint32_t)it, att + 1u);
             }
