@@ -6,7 +6,7 @@
 // 4 wave64, coalesced struct-of-arrays rows):
 //   k_step_coop   fused [gather by ancestor] + observation weight + SimStep, phase
 //                 by phase over a workgroup with rejected sampler attempts queued
-//                 in LDS (states up to H = 15)
+//                 in LDS (states up to H = 21)
 //   k_step        the same step with every rejection loop in its own thread (wide
 //                 states, injected / recorded variates)
 //   k_wsum        fixed-point weights: per-workgroup totals
@@ -1013,9 +1013,9 @@ static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + (QCAP + QCAP
 template <bool WEIGH>
 static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
 {
-    // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 15 four workgroups share a CU and it is
-    // the faster one (rollouts at H = 14: 2.4 vs 2.0e9 particle-steps/s); wider states leave it one or two workgroups
-    // per CU and the per-thread kernel wins (H = 28: 0.72 vs 1.14e9, H = 56: 0.25 vs 0.70e9).
+    // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 14 four workgroups share a CU, up to H = 21
+    // three, and it is the faster one (rollouts: H = 14 3.4 vs 2.5e9 particle-steps/s, H = 21 1.97 vs 1.67e9); wider
+    // states leave it two workgroups or one and the per-thread kernel wins (H = 28: 1.08 vs 1.33e9, H = 56: 0.26 vs 0.79e9).
     // The cooperative kernel takes the square root of the observation variance without the power-of-two scaling that
     // arguments below 2^-767 need; the argument is a positive integer times p (1 - p), so a parameter set with a test
     // probability in (0, 2^-700) always runs the per-thread kernel.
@@ -1024,7 +1024,7 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         return hipGetLastError();
     }
     const size_t lds = coop_lds_bytes(c->P.H);
-    if (!c->tiny_p && (g_coop == 2 || (g_coop == 1 && lds <= 40 * 1024))) {
+    if (!c->tiny_p && (g_coop == 2 || (g_coop == 1 && lds <= 53 * 1024))) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_coop<WEIGH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
