@@ -115,6 +115,7 @@ SIGNATURES = {
     "epi_mean_from_sums": (C.c_int, [C.POINTER(epi_params), C.c_int64, _i64p, _i64p, _i64p, _i64p, _i64p]),
     "epi_belief_suminf_quantiles": (C.c_int, [_vp, _vp, _f64p, C.c_int, _i64p]),
     "epi_belief_sample": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _i64p, _i64p, _i64p, _i64p]),
+    "epi_belief_sample_many": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int64, _i64p, _i64p, _i64p, _i64p]),
     "epi_ctx_stream": (_vp, [_vp]),
     "epi_pf_update_async": (C.c_int, [_vp, _vp, C.c_double, C.c_int64, C.c_uint64, C.c_uint32]),
     "epi_pf_collect": (C.c_int, [_vp, _vp, _f64p, _f64p, _u32p]),

@@ -3789,6 +3789,58 @@ int epi_belief_sample(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr, in
     });
 }
 
+// `count` particles uniformly at random, element j with the stream (seed, ctr0 + j) of epi_belief_sample: one launch
+// gathers their rows into a packed buffer, one copy brings them to the host.
+__global__ __launch_bounds__(TPB) void k_sample_many(int64_t count, int64_t n, uint64_t seed, uint64_t ctr0, const int32_t* __restrict__ src, int64_t stride,
+                                                      const int32_t* __restrict__ anc, int rows, int32_t* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (j >= count) return;
+    const Rng g = rng_make(seed, ctr0 + (uint64_t)j, 0);
+    uint32_t w[4];
+    rng_block(g, K_INIT, 0x300u, 0, w);
+    const uint64_t r53 = (((uint64_t)(w[0] >> 5)) << 26) | (uint64_t)(w[1] >> 6);
+    // floor(r53 n / 2^53) from the 128-bit product
+    const uint64_t lo = r53 * (uint64_t)n, hi = __umul64hi(r53, (uint64_t)n);
+    const int64_t slot = (int64_t)((hi << 11) | (lo >> 53));
+    const int64_t col = anc ? (int64_t)anc[slot] : slot;
+    for (int r = 0; r < rows; r++) out[j * rows + r] = src[(int64_t)r * stride + col];
+}
+
+int epi_belief_sample_many(epi_ctx* c, epi_belief* b, uint64_t seed, uint64_t ctr0, int64_t count, int64_t* S, int64_t* I, int64_t* R, int64_t* T)
+{
+    return guarded("epi_belief_sample_many", [&]() -> int {
+        int rc = belief_check(b, "epi_belief_sample_many");
+        if (rc) return rc;
+        if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_belief_sample_many: the belief belongs to another context");
+        if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_sample_many: a phased update is in progress");
+        if (count < 1 || count > (1LL << 24)) return fail(EPI_EINVAL, "epi_belief_sample_many: count = %lld not in [1, 2^24]", (long long)count);
+        HIPCHECK(hipSetDevice(c->device));
+        const int H = c->P.H, D = c->P.D, D1 = D + 1, rows = b->rows;
+        DevBuf d;
+        if (d.alloc(sizeof(int32_t) * (size_t)count * (size_t)rows) != hipSuccess) return fail(EPI_ENOMEM, "epi_belief_sample_many: hipMalloc failed");
+        k_sample_many<<<dim3((unsigned)ceil_div(count, TPB)), dim3(TPB), 0, c->stream>>>(count, b->n, seed, ctr0, b->buf[b->cur], b->stride,
+                                                                                         b->has_anc ? b->anc : nullptr, rows, d.as<int32_t>());
+        HIPCHECK(hipGetLastError());
+        std::vector<int32_t> h((size_t)count * (size_t)rows);
+        HIPCHECK(hipMemcpyAsync(h.data(), d.p, sizeof(int32_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        for (int64_t j = 0; j < count; j++) {
+            const int32_t* p = h.data() + (size_t)j * (size_t)rows;
+            if (S) S[j] = p[0];
+            if (R) R[j] = p[1];
+            if (I) for (int i = 0; i < H; i++) I[j * H + i] = p[2 + i];
+            if (T) {
+                int64_t* t = T + j * (int64_t)D1 * H;
+                for (int q = 0; q < D1 * H; q++) t[q] = 0;
+                for (int cidx = 1; cidx < H; cidx++)
+                    for (int r = 0; r < D; r++) t[cidx * D1 + r] = p[tests_row(H, r, cidx)];
+            }
+        }
+        return EPI_OK;
+    });
+}
+
 // ---- one population sharded over several devices, driven by one host thread ------------------------
 // epi_mctx holds G shards (an epi_ctx and an epi_belief each, shard g = global slots [n g / G, n (g + 1) / G)) and runs
 // the phased update over them: the host never waits between the phases of one shard, only once per update for the

@@ -177,6 +177,18 @@ def rand(b: ParticleCollection, seed: int = _DEFAULT_SEED, ctr: int = 0) -> Stat
     return State(S.value, I, R.value, T.T.copy(), b.prev_action)
 
 
+def rand_many(b: ParticleCollection, count: int, seed: int = _DEFAULT_SEED, ctr0: int = 0) -> List[State]:
+    """rand(rng, b, count): `count` particles uniformly at random in one device launch and one copy; element j is
+    rand(b, seed, ctr0 + j).  (A tree search draws thousands of states from one belief, test/POMCPOWtest.jl:15-21.)"""
+    p = b.ctx.pomdp
+    H, D1 = p.horizon, p.test_delay + 1
+    S = np.empty(count, dtype=np.int64); R = np.empty(count, dtype=np.int64)
+    I = np.empty((count, H), dtype=np.int64)
+    T = np.empty((count, H, D1), dtype=np.int64)
+    check(b.ctx.lib.epi_belief_sample_many(b.ctx.handle, b.handle, seed, ctr0, count, as_i64p(S), as_i64p(I), as_i64p(R), as_i64p(T)))
+    return [State(int(S[j]), I[j].copy(), int(R[j]), T[j].T.copy(), b.prev_action) for j in range(count)]
+
+
 def initialbelief(pomdp: CovidPOMDP, np_: int, mu: float = 10_000.0, sigma: float = 5_000.0, seed: int = _DEFAULT_SEED,
                   device: int = 0) -> ParticleCollection:
     """initialbelief(pomdp, np) (src/updater.jl:1-3) with initialstate(pomdp)

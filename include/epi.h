@@ -344,6 +344,12 @@ int epi_belief_suminf_quantiles(epi_ctx *ctx, epi_belief *b, const double *q, in
  * samples states from the belief). */
 int epi_belief_sample(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr,
                       int64_t *S, int64_t *I, int64_t *R, int64_t *T);
+/* `count` such particles in one launch and one copy: element j is the particle epi_belief_sample returns for
+ * (seed, ctr0 + j).  For planners that draw thousands of states from one belief (POMCPOW with tree_queries = 5000,
+ * test/POMCPOWtest.jl:15-21): S[count], R[count], I[count * H] particle-major, T[count * (D+1) * H] per particle as in
+ * epi_belief_download; any of them may be NULL.  count <= 2^24. */
+int epi_belief_sample_many(epi_ctx *ctx, epi_belief *b, uint64_t seed, uint64_t ctr0, int64_t count,
+                           int64_t *S, int64_t *I, int64_t *R, int64_t *T);
 
 /* ---- the closed loop, several days per call -------------------------------------- */
 

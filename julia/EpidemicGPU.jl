@@ -10,7 +10,8 @@
 #   s     = mean(b)                                        # src/updater.jl:23, used by src/MPC.jl:322
 #
 # Written without a Julia installation at hand: every ccall below is checked, argument type by argument type, against
-# the ctypes table the GPU test suite runs on (tests/test_julia_glue.py), but the file itself has not been executed.
+# the ctypes table the GPU test suite runs on, and every Module.name against the imports (tests/test_julia_glue.py), but
+# the file itself has not been executed.
 module EpidemicGPU
 
 using Distributions, Random
@@ -19,7 +20,7 @@ import Statistics: mean
 using EpidemicModeling: CovidPOMDP, State, Action
 
 export EpiCtx, GPUBelief, GPUBootstrapFilter, GPUNodeFilter, initialbelief, upload!, gen!, score_sequences, closed_loop_days!,
-       SimulateClosedLoop, unity_test_period, step_variates
+       SimulateClosedLoop, unity_test_period, step_variates, suminf_quantiles, gen_on_device!
 
 const LIBEPI = get(ENV, "EPI_GFX950_LIB", joinpath(@__DIR__, "..", "epidemicmodeling_amd", "csrc", "libepi_gfx950.so"))
 const EPI_MAX_H = 64
@@ -174,6 +175,15 @@ function Base.rand(rng::AbstractRNG, b::GPUBelief)
     State(S[], I, R[], T, b.prev_action)
 end
 
+# rand(rng, b, k): k states in one launch and one copy (a tree search draws thousands from one belief, test/POMCPOWtest.jl:15-21)
+function Base.rand(rng::AbstractRNG, b::GPUBelief, k::Integer)
+    H, D1 = dims(b)
+    S = Vector{Int64}(undef, k); R = Vector{Int64}(undef, k); I = Matrix{Int64}(undef, H, k); T = Array{Int64,3}(undef, D1, H, k)
+    check(ccall((:epi_belief_sample_many, LIBEPI), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, UInt64, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+                b.ctx.h, b.h, rand(rng, UInt64), 0, k, S, I, R, T))
+    [State(S[j], I[:, j], R[j], T[:, :, j], b.prev_action) for j in 1:k]
+end
+
 # order statistics of sum(I) over the belief (what src/plots.jl:40-54 would draw of a belief history)
 function suminf_quantiles(b::GPUBelief, q::Vector{Float64})
     length(q) <= 4 || error("at most 4 quantiles per call")
@@ -203,6 +213,21 @@ function POMDPs.gen(ctx::EpiCtx, s::State, a::Action, seed::Integer, step::Integ
         o = res.o[1]; rsum += res.r[1]
     end
     (sp = ParticleFilters.particles(b)[1], o = o, r = rsum)
+end
+
+# The method the reference's callers dispatch on, POMDPs.gen(pomdp, s, a, rng) (src/POMDPsInterface.jl:1): defined for
+# CovidPOMDP only after gen_on_device!(pomdp) has been called, since it replaces the package's own method.  The rng
+# argument supplies the seed of the counter-based streams (the reference ignores it and draws from the global RNG,
+# src/simulate.jl:40,58,79).
+const GEN_CTX = Dict{UInt64,EpiCtx}()
+function gen_on_device!(m::CovidPOMDP; device::Integer = 0)
+    GEN_CTX[objectid(m)] = EpiCtx(m; device = device)
+    @eval function POMDPs.gen(m::CovidPOMDP, s::State, a::Action, rng::AbstractRNG = Random.GLOBAL_RNG)
+        ctx = get(GEN_CTX, objectid(m), nothing)
+        ctx === nothing && error("gen_on_device!(pomdp) has not been called for this model")
+        POMDPs.gen(ctx, s, a, rand(rng, UInt64), 0)
+    end
+    m
 end
 
 # Simulate / SimulateEnsemble (src/simulate.jl:175-227): hist[4, T, n] = S, sum(I), R before each day, sum(pos) of the day
@@ -248,26 +273,35 @@ end
 # Simulate(T, state, b, pomdp, planner) with the belief on the device.  `planner` is anything with
 # POMDPs.action(planner, b::GPUBelief); an MPC controller plans on the belief mean as in src/MPC.jl:322:
 #     POMDPs.action(mpc::MPC, b::GPUBelief) = POMDPs.action(mpc, mean(b))
-function SimulateClosedLoop(T::Int, state::State, b::GPUBelief, pomdp::CovidPOMDP, planner; seed::Integer = 0x5EED)
+# Instead of the reference's beliefHist (a ParticleCollection per day, src/POMDPsInterface.jl:53) the result carries,
+# per day, what src/plots.jl:47 draws of it: the column sums of the posterior (belief_sums[:, d] ./ n is its mean: S, R,
+# I[1..H], Tests) and the order statistics `q` of sum(I) over its particles (belief_quant[:, d]).
+function SimulateClosedLoop(T::Int, state::State, b::GPUBelief, pomdp::CovidPOMDP, planner; seed::Integer = 0x5EED,
+                            q::Vector{Float64} = [0.05, 0.5, 0.95])
     up = GPUBootstrapFilter(b.ctx, b.n, UInt64(seed), UInt32(0), NaN, NaN, UInt32(0))
     truth = GPUBelief(b.ctx, [state])
     sus = zeros(Int, T); inf = zeros(Int, T); rec = zeros(Int, T); tests = zeros(Int, T)
     acts = Vector{Action}(undef, T); rewards = zeros(Float64, T)
+    H, D1 = dims(b)
+    belief_sums = zeros(Int64, 2 + H + D1 * H, T); belief_quant = zeros(Int64, length(q), T)
     cur = (state.S, sum(state.I), state.R)
     day = 1
     while day <= T                                                  # src/POMDPsInterface.jl:41-60
         action = POMDPs.action(planner, b)                          # (day-1) % test_period == 0 here
         k = min(pomdp.test_period, T - day + 1)
-        res = closed_loop_days!(truth, b, up, fill(action.testing_prop, k), xor(UInt64(seed), 0x7275E), day - 1)
+        res = closed_loop_days!(truth, b, up, fill(action.testing_prop, k), xor(UInt64(seed), 0x7275E), day - 1; q = q, want_sums = true)
         for j in 1:k
             d = day + j - 1
             sus[d], inf[d], rec[d] = cur
             cur = (res.true_sir[1, j], res.true_sir[2, j], res.true_sir[3, j])
             acts[d] = action; rewards[d] = res.r[j]; tests[d] = res.o[j]
+            belief_sums[:, d] = res.sums[:, j]
+            isempty(q) || (belief_quant[:, d] = res.quant[:, j])
         end
         day += k
     end
-    (sus = sus, inf = inf, rec = rec, N = pomdp.N, T = T, pos_test = tests, actions = acts, rewards = rewards)
+    (sus = sus, inf = inf, rec = rec, N = pomdp.N, T = T, pos_test = tests, actions = acts, rewards = rewards,
+     belief_sums = belief_sums, belief_quant = belief_quant, quantiles = q)
 end
 
 # ---- one population over the GPUs of a node (epi_mctx) ------------------------------------------------------------

@@ -2,12 +2,18 @@
 # compares every integer of the resulting states (the check "integer compartment counts bit-exact against the
 # reference step function fed the same draws").  Needs Julia, the reference package and its dependencies, and a GPU:
 #
-#     julia --project=/path/to/EpidemicModeling parity.jl [n_particles] [days]
+#     julia --project=/path/to/EpidemicModeling parity.jl [n_particles] [days] [data_dir]
+#
+# data_dir holds the two files the reference constructor reads and its checkout lacks (src/typedef.jl:88-96;
+# .MISSING_LARGE_BLOBS): Sample50.csv and raw_viral_load.csv.  epidemicmodeling_amd.paramfit.write_csvs(data_dir, seed)
+# regenerates them from the model of src/Python/distUtils.py; without the argument the constructor's own default
+# paths (src/data/) are used.
 #
 # The reference draws, per step, sympt[1..H] (simulate.jl:58), pos[1..H] (:79) and gam[1..H] (:40, through RVsum,
 # init.jl:71-78, whose zero-shape branch draws from Normal(0, 0)), in that order, from the global RNG.  The three `rand`
 # methods below pop those draws from a queue instead.
 using EpidemicModeling, Distributions, Random
+import ParticleFilters
 using EpidemicModeling: SimStep, State, Action, CovidPOMDP
 include(joinpath(@__DIR__, "EpidemicGPU.jl"))
 using .EpidemicGPU
@@ -28,8 +34,10 @@ function check_particle(m::CovidPOMDP, s::State, a::Action, sympt, pos, gam, sp_
     pos_tests == pos
 end
 
-function main(n = 2000, days = 20; seed = 0x5EED)
-    m = CovidPOMDP()
+function main(n = 2000, days = 20, data_dir = nothing; seed = 0x5EED)
+    # keyword names of the constructor: src/typedef.jl:78-93
+    m = data_dir === nothing ? CovidPOMDP() :
+        CovidPOMDP(infections_path = joinpath(data_dir, "Sample50.csv"), viral_loads_path = joinpath(data_dir, "raw_viral_load.csv"))
     up = GPUBootstrapFilter(unity_test_period(m), n; seed = seed)
     b = initialbelief(up)
     bad = 0
@@ -48,5 +56,6 @@ function main(n = 2000, days = 20; seed = 0x5EED)
 end
 
 if abspath(PROGRAM_FILE) == @__FILE__
-    main(length(ARGS) >= 1 ? parse(Int, ARGS[1]) : 2000, length(ARGS) >= 2 ? parse(Int, ARGS[2]) : 20)
+    main(length(ARGS) >= 1 ? parse(Int, ARGS[1]) : 2000, length(ARGS) >= 2 ? parse(Int, ARGS[2]) : 20,
+         length(ARGS) >= 3 ? ARGS[3] : nothing)
 end

@@ -217,6 +217,34 @@ def test_belief_mean_and_sample():
     assert hits.size >= 1
 
 
+def test_many_samples_in_one_call_equal_single_calls():
+    """rand(b, count): element j is the particle a single call returns for (seed, ctr0 + j) -- on an uploaded belief and
+    on one that an update left with a pending ancestor indirection (test_delay 2: pending-test rows included) -- and
+    the draws are uniform over the particles."""
+    pomdp = em.make_pomdp(LOD=5, test_delay=2)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    st = random_states(pomdp, 5000, np.random.default_rng(43))
+    b = _belief(pomdp, st)
+    for updated in (False, True):
+        if updated:
+            _, mu, _ = orc.log_weights(st, 0.3, 0)
+            em.update(em.BootstrapFilter(pomdp, 5000, seed=SEED), b, em.Action(0.3), int(np.median(mu)))
+        many = em.rand_many(b, 300, seed=77, ctr0=1000)
+        for j in (0, 1, 17, 150, 299):
+            one = em.rand(b, seed=77, ctr=1000 + j)
+            assert (one.S, one.R) == (many[j].S, many[j].R) and (one.I == many[j].I).all() and (one.Tests == many[j].Tests).all()
+    S, I, R, T = b.download()
+    idx = []
+    for s in em.rand_many(b, 20_000, seed=5):
+        hit = np.flatnonzero((S == s.S) & (R == s.R) & (I == s.I).all(axis=1))
+        assert hit.size >= 1
+        idx.append(hit[0])
+    # resampled beliefs hold duplicates: compare the hit frequencies of the distinct particles with their multiplicities
+    assert len(set(idx)) > 0.5 * len(np.unique(np.column_stack([S, R, I]), axis=0))
+    with pytest.raises(EpiError):
+        em.rand_many(b, 0)
+
+
 # ---------------------------------------------------------------------------
 # the filter update
 # ---------------------------------------------------------------------------

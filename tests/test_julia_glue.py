@@ -74,7 +74,7 @@ def test_every_ccall_matches_the_c_abi():
 def test_the_entry_points_a_drop_in_needs_are_bound():
     bound = {name for name, _, _ in _ccalls(SRC)}
     for name in ("epi_ctx_create", "epi_params_set", "epi_belief_create", "epi_belief_upload", "epi_belief_download", "epi_belief_copy",
-                 "epi_belief_init_normal", "epi_pf_update", "epi_belief_mean", "epi_belief_sample", "epi_step_batch", "epi_rollout_batch",
+                 "epi_belief_init_normal", "epi_pf_update", "epi_belief_mean", "epi_belief_sample", "epi_belief_sample_many", "epi_step_batch", "epi_rollout_batch",
                  "epi_rollout_score", "epi_closed_loop_days", "epi_step_variates", "epi_mctx_create", "epi_mpf_update", "epi_mctx_mean", "epi_mctx_download", "epi_belief_suminf_quantiles", "epi_last_error"):
         assert name in bound, name
 
@@ -99,6 +99,8 @@ def test_the_reference_interface_is_defined():
                     r"function mean\(b::GPUBelief", r"function Base\.rand\(rng::AbstractRNG, b::GPUBelief\)",
                     r"ParticleFilters\.n_particles\(b::GPUBelief\)", r"function ParticleFilters\.particles\(b::GPUBelief\)",
                     r"function initialbelief\(up::GPUBootstrapFilter", r"function POMDPs\.gen\(ctx::EpiCtx, s::State, a::Action",
+                    r"function POMDPs\.gen\(m::CovidPOMDP, s::State, a::Action, rng::AbstractRNG",
+                    r"function Base\.rand\(rng::AbstractRNG, b::GPUBelief, k::Integer\)",
                     r"function SimulateClosedLoop\(T::Int, state::State, b::GPUBelief, pomdp::CovidPOMDP, planner",
                     r"mutable struct GPUBelief <: ParticleFilters\.AbstractParticleBelief\{State\}",
                     r"mutable struct GPUBootstrapFilter <: POMDPs\.Updater"):
@@ -107,3 +109,35 @@ def test_the_reference_interface_is_defined():
     for pattern in (r"Base\.rand\(::Random\.AbstractRNG, ::Distributions\.Binomial\)", r"Base\.rand\(::Random\.AbstractRNG, ::Distributions\.Gamma\)",
                     r"Base\.rand\(::Random\.AbstractRNG, ::Distributions\.Normal\)", r"SimStep\(deepcopy\(s\), m, a\)", r"step_variates\(b, a, seed, day\)"):
         assert re.search(pattern, harness), pattern
+
+
+def _module_names(src):
+    """names a file makes available: `using A, B`, `import A, B`, `import A: x`, `using A: x` (module A itself only for plain forms),
+    and modules defined or included under a `using .X`"""
+    have = {"Base", "Core", "Main", "GC"}
+    for m in re.finditer(r"^\s*(using|import)\s+([^\n#]+)", src, re.M):
+        rest = m.group(2)
+        if ":" in rest:
+            mod, names = rest.split(":", 1)
+            if m.group(1) == "import":
+                have.add(mod.strip().lstrip(".").split(".")[0])          # `import A: x` binds x only, but `A.x` is never written then
+            have.update(n.strip() for n in names.split(","))
+        else:
+            have.update(n.strip().lstrip(".").split(".")[0] for n in rest.split(","))
+    have.update(re.findall(r"^\s*module\s+(\w+)", src, re.M))
+    return have
+
+
+def test_every_qualified_name_has_its_module_in_scope():
+    """`using EpidemicModeling` does not bring the names of the packages it depends on into scope: every Module.name
+    written in the two files needs an import / using of that module in the same file."""
+    for fname in ("EpidemicGPU.jl", "parity.jl"):
+        src = open(os.path.join(ROOT, "julia", fname)).read()
+        code = "\n".join(ln.split("#", 1)[0] for ln in src.splitlines())           # comments out
+        code = re.sub(r'"[^"\n]*"', '""', code)                                     # and string literals
+        have = _module_names(code)
+        used = set(re.findall(r"(?<![\w.])([A-Z]\w*)\.(?=[A-Za-z_@])", code))
+        # locals that look like modules: struct fields / variables starting with a capital letter
+        used -= {"S", "R", "I", "T", "C_NULL", "ENV", "ARGS", "QUEUE", "GEN_CTX"}
+        missing = {u for u in used if u not in have}
+        assert not missing, (fname, missing)
