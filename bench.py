@@ -35,6 +35,10 @@ VALU_ISSUE_CYCLES = {"valu_add_f64": 5.2, "valu_mul_f64": 5.6, "valu_fma_f64": 5
                      "valu_fma_f32": 4.7, "valu_int64": 7.2, "valu_int32": 2.7, "valu_trans_f32": 7.0, "other": 3.0}
 SEED = 0x5EED
 ACTION = 0.2
+import datetime
+# a rank that never arrives (or a collective that never completes) ends the others after this long
+GROUP_TIMEOUT = datetime.timedelta(seconds=float(os.environ.get("EPI_BENCH_GROUP_TIMEOUT", "900")))
+NODE_FILTER_TIMEOUT = float(os.environ.get("EPI_BENCH_NODE_FILTER_TIMEOUT", "420"))
 
 
 def alg_bytes_per_particle_step(H: int, D: int) -> int:
@@ -138,6 +142,61 @@ def run_single(args):
     return pomdp, n, dt, ksum.value / max(kcnt.value, 1), dict(loglik=ll.value, ess=ess.value, flags=fl.value)
 
 
+def run_node_filter_child(args):
+    """--node-filter-child: the same population and observations through the library's own sharded update
+    (epi_mctx_create + epi_mpf_update of include/epi.h: one host thread drives every device; the form a single-process
+    host such as the reference's Julia session binds).  One shard per device 0 .. N-1 with the small exchanges over
+    RCCL; EPI_BENCH_NODE_DEVICES="0,0" names the shards' devices instead (a repeated device: exchanges without RCCL),
+    for boxes with fewer devices than shards.  Prints one JSON object."""
+    import epidemicmodeling_amd as em
+    from epidemicmodeling_amd.distributed import NodeFilter
+    names = os.environ.get("EPI_BENCH_NODE_DEVICES")
+    devices = [int(x) for x in names.split(",")] if names else list(range(args.gpus))
+    rccl = len(set(devices)) == len(devices)
+    pomdp = em.make_pomdp()
+    n = args.particles
+    obs = observations(pomdp, args.warmup + args.steps)
+    f = NodeFilter(pomdp, n, devices, seed=SEED, rccl=rccl)
+    f.init_normal(10_000.0, 5_000.0)
+    for t in range(args.warmup):
+        f.update(ACTION, obs[t])
+    f.sums()                                        # places what the last warm-up update left in flight, and waits
+    over0 = f.overlapped_updates
+    moved = 0
+    t0 = time.perf_counter()
+    for t in range(args.warmup, args.warmup + args.steps):
+        info = f.update(ACTION, obs[t])
+        moved += info["moved"]
+    f.sums()                                        # the last update's particle exchange belongs to the timed region
+    dt = time.perf_counter() - t0
+    res = {"entry_points": "epi_mctx_create + epi_mpf_update (one process, one host thread)", "shards": len(devices),
+           "devices": devices, "rccl_devices": len(devices) if rccl else 0, "particles": n, "steps": args.steps,
+           "ms_per_step": dt / args.steps * 1e3, "value": n * args.steps / dt, "unit": "particle-steps/s",
+           "moved": moved / args.steps, "overlapped_updates": f.overlapped_updates - over0,
+           "diagnostics": dict(loglik=info["loglik"], ess=info["ess"], flags=info["flags"])}
+    f.close()
+    return res
+
+
+def node_filter_block(args):
+    """Rank 0, before it joins the process group (and before it touches a device): the library's one-process sharded
+    update, timed in a child process of its own on the same N devices while the other ranks wait at the rendezvous.
+    A failure there is reported inside the block and does not stop the benchmark."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, "-u", os.path.abspath(__file__), "--node-filter-child", "--gpus", str(args.gpus),
+           "--particles", str(args.particles), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=NODE_FILTER_TIMEOUT)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result after {NODE_FILTER_TIMEOUT:.0f} s"}
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        return {"error": f"exit status {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-600:]}
+    return json.loads(lines[0])
+
+
 def free_port():
     import socket
     with socket.socket() as s:
@@ -147,22 +206,49 @@ def free_port():
 
 def spawn_ranks(args):
     """`bench.py --gpus N` started without a launcher: this process starts the N ranks itself (fresh interpreters,
-    before anything here has touched a GPU), one device each, waits for all of them and hands on rank 0's JSON line.
-    Returns the exit status for the parent."""
+    before anything here has touched a GPU), one device each, and hands on rank 0's JSON line.  The ranks are watched
+    together: when one of them fails, or the whole run takes longer than EPI_BENCH_TIMEOUT seconds, the others (which
+    would wait for it in a collective) are ended too.  What the other ranks print goes to stderr.  Returns the exit
+    status for the parent."""
     import subprocess
+    import tempfile
     port = free_port()
+    limit = float(os.environ.get("EPI_BENCH_TIMEOUT", "1800"))
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EPI_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if any(codes):
-        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+                                      stdout=out0 if r == 0 else sys.stderr))
+    t0 = time.monotonic()
+    why = None
+    while why is None:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c for c in codes):
+            why = f"rank {[i for i, c in enumerate(codes) if c][0]} failed"
+        elif time.monotonic() - t0 > limit:
+            why = f"no result after {limit:.0f} s"
+        else:
+            time.sleep(0.1)
+    if why is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    codes = [p.returncode for p in procs]
+    if why is not None or any(codes):
+        sys.stderr.write(f"bench.py: {why or 'a rank failed'}; rank exit codes {codes}\n")
         return 1
-    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    out0.seek(0)
+    lines = [ln for ln in out0.read().decode().splitlines() if ln.startswith("{")]
     if len(lines) != 1:
         sys.stderr.write("bench.py: rank 0 did not print exactly one JSON line\n")
         return 1
@@ -186,11 +272,11 @@ def init_group(args):
         if ndev < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} devices, this host shows {ndev}")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=GROUP_TIMEOUT)
     else:
         if ndev:
             torch.cuda.set_device(local)
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=GROUP_TIMEOUT)
     world = dist.get_world_size()
     if world != args.gpus:
         dist.destroy_process_group()
@@ -263,9 +349,21 @@ def main():
                     help="after the timed region, run one gather dispatch of known traffic (PMC calibration)")
     ap.add_argument("--launch-check", action="store_true",
                     help="start the ranks, check the process group and leave without device work")
+    ap.add_argument("--node-filter-child", action="store_true",
+                    help="(internal) time the library's one-process sharded update on devices 0 .. N-1 and print its block")
+    ap.add_argument("--no-node-filter", action="store_true", help="with --gpus N > 1: skip the node_filter block")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.node_filter_child:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)                                   # RCCL's banner and the like: to stderr
+        res = run_node_filter_child(args)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(res), flush=True)
+        return
 
     # no launcher around us: start the ranks here, before this process touches a GPU
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -278,6 +376,9 @@ def main():
     os.dup2(2, 1)
 
     rank, world, backend = 0, 1, "none (one process, one device)"
+    node_filter = None
+    if args.gpus > 1 and not args.launch_check and not args.no_node_filter and int(os.environ.get("RANK", "0")) == 0:
+        node_filter = node_filter_block(args)
     if args.launch_check:
         res = run_launch_check(args)
         sys.stdout.flush()
@@ -334,6 +435,10 @@ def main():
         "issue": issue,
         "diagnostics": diag,
     }
+    if node_filter is not None:
+        # `value` above is the one-process-per-GPU form (torch.distributed ranks, ShardedFilter); this block is the same
+        # update through the C ABI's own sharded entry points, one process driving all N devices
+        out["node_filter"] = node_filter
     if args.gpus == 1 and not args.no_cpu:
         out["cpu_baseline_single_thread"] = cpu_baseline(pomdp, seconds_target=4.0, threads=1, n=100_000)
         out["cpu_baseline"] = cpu_baseline(pomdp)

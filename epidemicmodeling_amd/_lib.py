@@ -128,6 +128,7 @@ SIGNATURES = {
 TESTING_SIGNATURES = {
     "epi_debug_screen": (C.c_int, [C.c_int]),
     "epi_debug_step_impl": (C.c_int, [C.c_int]),
+    "epi_debug_node_exchange": (C.c_int, [C.c_int]),
     "epi_debug_f32_forms": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_uint64)]),
     "epi_debug_btrs_quick": (C.c_int, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_double, C.c_int, C.POINTER(C.c_uint64)]),
 }

@@ -53,9 +53,11 @@ static thread_local std::string g_err;
 #ifdef EPI_TESTING
 static int g_screen = 1;     // see epi_debug_screen
 static int g_coop = 1;       // see epi_debug_step_impl: 0 per-thread, 1 by state width, 2 cooperative
+static int g_node_exchange = 0;   // see epi_debug_node_exchange: bit 0 peer copies between shards of one device, bit 1 maximum through the host
 #else
 constexpr int g_screen = 1;
 constexpr int g_coop = 1;
+constexpr int g_node_exchange = 0;
 #endif
 
 static int fail(int code, const char* fmt, ...)
@@ -160,6 +162,7 @@ struct epi_belief {
     // bookkeeping of the phased update: columns that received an ancestor in the update in progress, columns that
     // still wait for one after epi_pf_finish, columns the step of the next update has covered so far
     bool cum_ready = false;             // the update in progress has written its cumulative weights (over the log weights)
+    bool selected = false;              // epi_pf_select_local has run in the update in progress (once per update)
     bool flags_delivered = false;       // ... and handed its step flags over with the weight totals (device flags are clear again)
     std::vector<Span> filled, unfilled, done;
     double part_a = 0.0; int64_t part_o = 0;                // arguments of the first epi_pf_predict_part of an update
@@ -169,7 +172,7 @@ struct epi_belief {
 static inline void protocol_reset(epi_belief* b)
 {
     b->phase = PH_IDLE;
-    b->filled.clear(); b->unfilled.clear(); b->done.clear();
+    b->filled.clear(); b->unfilled.clear(); b->done.clear(); b->selected = false;
 }
 
 static bool spans_overlap(const std::vector<Span>& v, int64_t a, int64_t b)
@@ -764,6 +767,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // One barrier per round: round r reads the entries of queue (r-1) mod 2, counted in qn[(r-1) mod 3], and pushes
     // its rejected draws to queue r mod 2, counted in qn[r mod 3]; thread 0 clears qn[(r+1) mod 3] for the round after
     // (it was last read in round r-1, before this round's barrier).
+    // `spare` is the count the rounds leave at zero and that no thread of the last round reads (a thread that is through
+    // must not clear the count a slower one has yet to read): the infection terms' queue starts there.
+    int spare = 1;
     {
         int cur = 0;                                                               // (round - 1) mod 3
         const double* __restrict__ lf_t = Dp->lf.t;
@@ -779,11 +785,15 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 #pragma unroll
                 for (int w = 0; w < CTPB / 64; w++) { cnt += qw[w]; seg_end[w] = cnt; }
             } else cnt = qn[cur] < qcap_cur ? qn[cur] : qcap_cur;
-            if (cnt == 0u) break;
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            spare = nxt;
+            if (cnt == 0u) {                                                       // uniform
+                if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;                     // read a round ago: every thread is past it
+                break;
+            }
 #ifdef EPI_PHASE_STAMPS
             if (tid == 0) { atomicAdd(&g_phase[8], 1ULL); atomicAdd(&g_phase[9], (unsigned long long)cnt); if (round == 1u) atomicAdd(&g_phase[10], (unsigned long long)cnt); if (round == 2u) atomicAdd(&g_phase[11], (unsigned long long)cnt); }
 #endif
-            const int nxt = cur == 2 ? 0 : cur + 1;
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
             unsigned short* qnext = (round & 1u) ? q1 : q0;
@@ -839,7 +849,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             cur = nxt;
         }
     }
-    if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }                           // the count a slower thread may still be reading is zero already
+    // the last round's readers of the first queue's entries are through before phase D pushes to it
     __syncthreads();
 
     EPI_STAMP(2);
@@ -909,7 +919,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 }
             }
         }
-        const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[0], QCAP);
+        const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[spare], QCAP);
         if (gfail && !gpushed) g_over |= 1ULL << it;                               // queue full: finished after the loop
     }
     while (g_over) {
@@ -922,7 +932,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 
     // ---- E: gamma rounds (round r runs attempt r - 1 in full) ----------------------------------------------------
     {
-        int cur = 0;
+        int cur = spare;
 #pragma unroll 1
         for (uint32_t round = 1; round <= COOP_GAMMA_ROUNDS; round++) {
             __syncthreads();
@@ -959,6 +969,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             cur = nxt;
         }
     }
+    __syncthreads();                                                               // the terms other threads have drawn for this one
 
     EPI_STAMP(4);
     // ---- F: infection sum in bin order, new infections, outputs --------------------------------
@@ -2179,6 +2190,15 @@ static int belief_check(const epi_belief* b, const char* who)
     return EPI_OK;
 }
 
+// the phased calls and the summaries name the context next to the belief: it must be the belief's own
+static int shard_check(const epi_ctx* c, const epi_belief* b, const char* who)
+{
+    int rc = belief_check(b, who);
+    if (rc) return rc;
+    if (!c || b->ctx != c) return fail(EPI_EINVAL, "%s: belief belongs to another context", who);
+    return EPI_OK;
+}
+
 int epi_belief_create(epi_ctx* c, int64_t n_local, int64_t halo_cap, epi_belief** out)
 {
     return guarded("epi_belief_create", [&]() -> int {
@@ -2944,6 +2964,7 @@ static int launch_weigh(epi_ctx* c, epi_belief* b, const double* d_lwmax_global 
 {
     b->halo_used = 0;                   // the halo of the buffer this update writes starts empty
     b->filled.clear();
+    b->selected = false;
     k_wsum<false><<<dim3((unsigned)b->nblocks), dim3(TPB), 0, c->stream>>>(b->n, b->lw, b->scal, b->frac_bits, b->blocksum, b->blocksq, d_lwmax_global);
     k_wscan<<<1, 1024, 0, c->stream>>>(b->nblocks, b->blocksum, b->blocksq, b->scal, b->big, 0, d_lwmax_global, d_totals);
     HIPCHECK(hipGetLastError());
@@ -2985,9 +3006,8 @@ static int launch_scatter(epi_ctx* c, epi_belief* b, unsigned long long W, unsig
 
 static int update_checks(epi_ctx* c, epi_belief* b, const char* who)
 {
-    int rc = belief_check(b, who);
+    int rc = shard_check(c, b, who);
     if (rc) return rc;
-    if (!c || b->ctx != c) return fail(EPI_EINVAL, "%s: belief belongs to another context", who);
     if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "%s: a phased update is in progress", who);
     if (b->n_total != b->n || b->slot0 != 0) return fail(EPI_ESTATE, "%s: belief is a shard; use the phased calls", who);
     return EPI_OK;
@@ -3032,14 +3052,15 @@ static inline uint32_t weight_flags(unsigned long long w_total, int64_t n_total)
     return (double)n_total > 1e-3 * (double)w_total ? EPI_F_COARSE_W : 0u;
 }
 
-// diagnostics of the update whose scalars are `d`; waits for the stream, clears the flags
-static int collect_from(epi_ctx* c, epi_belief* b, DevScalars* d, double* loglik, double* ess, uint32_t* flags)
+// diagnostics of the update whose scalars are `d`; waits for the stream; clear: leaves the device flags zero for the
+// next update that accumulates into the same scalars (not wanted for scalars the next user zeroes itself)
+static int collect_from(epi_ctx* c, epi_belief* b, DevScalars* d, double* loglik, double* ess, uint32_t* flags, bool clear = true)
 {
     DevScalars h;
     if (int rs = read_scalars(c, d, &h)) return rs;
     const uint32_t f = h.flags | weight_flags(h.w_total, b->n_total);
     if (flags) *flags = f;
-    HIPCHECK(hipMemsetAsync(&d->flags, 0, sizeof(unsigned int), c->stream));
+    if (clear) HIPCHECK(hipMemsetAsync(&d->flags, 0, sizeof(unsigned int), c->stream));
     const double scale = ldexp(1.0, b->frac_bits);
     if (loglik) *loglik = h.w_total ? h.lwmax + log((double)h.w_total / scale / (double)b->n_total) - 0.91893853320467274178 : -INFINITY;
     if (ess) *ess = h.sumsq > 0.0 ? ((double)h.w_total * (double)h.w_total) / h.sumsq : 0.0;
@@ -3097,7 +3118,9 @@ int epi_pf_update_noalloc(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
     HIPCHECK(hipMemsetAsync(p, 0, 256, c->stream));
     rc = enqueue_update(c, b, sc, a, o, seed, step, false);
     if (rc) return rc;
-    return collect_from(c, b, sc.scal, loglik, ess, flags);
+    // nothing may be left queued on the shared array when this returns (the next call on this device, from any
+    // context, zeroes the scalars itself)
+    return collect_from(c, b, sc.scal, loglik, ess, flags, false);
 }
 
 #ifdef EPI_PHASE_STAMPS
@@ -3109,6 +3132,12 @@ int epi_debug_phase_times(unsigned long long* out)
 }
 #endif
 #ifdef EPI_TESTING
+int epi_debug_node_exchange(int mode)
+{
+    g_node_exchange = mode & 3;
+    return EPI_OK;
+}
+
 int epi_debug_step_impl(int cooperative)
 {
     g_coop = cooperative < 0 ? 0 : (cooperative > 2 ? 2 : cooperative);
@@ -3245,9 +3274,8 @@ float epi_last_predict_ms(epi_ctx* c)
 int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* lwmax_local)
 {
     return guarded("epi_pf_predict", [&]() -> int {
-        int rc = belief_check(b, "epi_pf_predict");
+        int rc = shard_check(c, b, "epi_pf_predict");
         if (rc) return rc;
-        if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_predict: belief belongs to another context");
         if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict: previous update not finished");
         HIPCHECK(hipSetDevice(c->device));
         rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
@@ -3262,7 +3290,7 @@ int epi_pf_predict(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed
 
 int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_local, double* sumsq_local, uint32_t* flags_local)
 {
-    int rc = belief_check(b, "epi_pf_weigh");
+    int rc = shard_check(c, b, "epi_pf_weigh");
     if (rc) return rc;
     if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh: call epi_pf_predict first");
     HIPCHECK(hipSetDevice(c->device));
@@ -3282,9 +3310,9 @@ int epi_pf_weigh(epi_ctx* c, epi_belief* b, double lwmax_global, uint64_t* w_loc
 int epi_pf_predict_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64_t seed, uint32_t step, double* d_lwmax_local)
 {
     return guarded("epi_pf_predict_dev", [&]() -> int {
-        int rc = belief_check(b, "epi_pf_predict_dev");
+        int rc = shard_check(c, b, "epi_pf_predict_dev");
         if (rc) return rc;
-        if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_dev: bad argument");
+        if (!d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_dev: NULL device pointer");
         if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_pf_predict_dev: previous update not finished");
         HIPCHECK(hipSetDevice(c->device));
         rc = launch_predict(c, b, own_scratch(b), a, o, seed, step);
@@ -3303,9 +3331,9 @@ int epi_pf_predict_part_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint
                             double* d_lwmax_local)
 {
     return guarded("epi_pf_predict_part_dev", [&]() -> int {
-        int rc = belief_check(b, "epi_pf_predict_part_dev");
+        int rc = shard_check(c, b, "epi_pf_predict_part_dev");
         if (rc) return rc;
-        if (!c || b->ctx != c || !d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_part_dev: bad argument");
+        if (!d_lwmax_local) return fail(EPI_EINVAL, "epi_pf_predict_part_dev: NULL device pointer");
         if (b->phase != PH_IDLE && b->phase != PH_PENDING && b->phase != PH_PARTIAL)
             return fail(EPI_ESTATE, "epi_pf_predict_part_dev: previous update not finished");
         if (col0 < 0 || count < 1 || col0 + count > b->n)
@@ -3335,7 +3363,7 @@ int epi_pf_predict_part_dev(epi_ctx* c, epi_belief* b, double a, int64_t o, uint
 
 int epi_pf_weigh_dev(epi_ctx* c, epi_belief* b, const double* d_lwmax_global, double* d_totals)
 {
-    int rc = belief_check(b, "epi_pf_weigh_dev");
+    int rc = shard_check(c, b, "epi_pf_weigh_dev");
     if (rc) return rc;
     if (!d_lwmax_global || !d_totals) return fail(EPI_EINVAL, "epi_pf_weigh_dev: NULL device pointer");
     if (b->phase != PH_PREDICTED) return fail(EPI_ESTATE, "epi_pf_weigh_dev: call epi_pf_predict_dev first");
@@ -3378,9 +3406,13 @@ int epi_pf_plan(int64_t n_total, int G, const uint64_t* w_shard, uint64_t seed, 
 static int epi_pf_select_local_body(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
                         int64_t slot_begin, int64_t slot_end)
 {
-    int rc = belief_check(b, "epi_pf_select_local");
+    int rc = shard_check(c, b, "epi_pf_select_local");
     if (rc) return rc;
+    if (!w_shard || G < 1 || shard < 0 || shard >= G) return fail(EPI_EINVAL, "epi_pf_select_local: bad shard arguments");
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_select_local: call epi_pf_weigh first");
+    // the pass leaves the update's cumulative weights and its list of long child ranges behind: a second one would
+    // append to that list and replay it
+    if (b->selected) return fail(EPI_ESTATE, "epi_pf_select_local: once per update (one range of owned slots)");
     if (slot_begin < b->slot0 || slot_end > b->slot0 + b->n || slot_begin > slot_end)
         return fail(EPI_EINVAL, "epi_pf_select_local: slots [%lld, %lld) not owned by this shard", (long long)slot_begin, (long long)slot_end);
     if (slot_begin == slot_end) return EPI_OK;
@@ -3390,6 +3422,7 @@ static int epi_pf_select_local_body(epi_ctx* c, epi_belief* b, int G, int shard,
     for (int g = 0; g < G; g++) { if (g < shard) off += w_shard[g]; total += w_shard[g]; }
     rc = launch_scatter(c, b, total, off, u, slot_begin, slot_end);
     if (rc) return rc;
+    b->selected = true;
     b->filled.emplace_back(slot_begin - b->slot0, slot_end - b->slot0);
     return EPI_OK;
 }
@@ -3403,8 +3436,9 @@ int epi_pf_select_local(epi_ctx* c, epi_belief* b, int G, int shard, const uint6
 int epi_pf_export(epi_ctx* c, epi_belief* b, int G, int shard, const uint64_t* w_shard, uint64_t seed, uint32_t step,
                   int64_t slot_begin, int64_t slot_end, void* dev_buf)
 {
-    int rc = belief_check(b, "epi_pf_export");
+    int rc = shard_check(c, b, "epi_pf_export");
     if (rc) return rc;
+    if (!w_shard || G < 1 || shard < 0 || shard >= G) return fail(EPI_EINVAL, "epi_pf_export: bad shard arguments");
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_export: call epi_pf_weigh first");
     if (slot_begin > slot_end || slot_begin < 0 || slot_end > b->n_total || !dev_buf) return fail(EPI_EINVAL, "epi_pf_export: bad slot range or NULL buffer");
     if (slot_begin == slot_end) return EPI_OK;
@@ -3449,9 +3483,8 @@ static int import_block(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t s
 
 static int epi_pf_import_body(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
 {
-    int rc = belief_check(b, "epi_pf_import");
+    int rc = shard_check(c, b, "epi_pf_import");
     if (rc) return rc;
-    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_import: belief belongs to another context");
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_import: call epi_pf_weigh first");
     return import_block(c, b, slot_begin, slot_end, dev_buf, false, "epi_pf_import");
 }
@@ -3463,9 +3496,8 @@ int epi_pf_import(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_en
 
 static int epi_pf_import_late_body(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t slot_end, const void* dev_buf)
 {
-    int rc = belief_check(b, "epi_pf_import_late");
+    int rc = shard_check(c, b, "epi_pf_import_late");
     if (rc) return rc;
-    if (!c || b->ctx != c) return fail(EPI_EINVAL, "epi_pf_import_late: belief belongs to another context");
     if (b->phase != PH_PENDING && b->phase != PH_PARTIAL) return fail(EPI_ESTATE, "epi_pf_import_late: no slot waits for an import");
     return import_block(c, b, slot_begin, slot_end, dev_buf, true, "epi_pf_import_late");
 }
@@ -3477,7 +3509,7 @@ int epi_pf_import_late(epi_ctx* c, epi_belief* b, int64_t slot_begin, int64_t sl
 
 static int epi_pf_finish_body(epi_ctx* c, epi_belief* b, uint32_t* flags)
 {
-    int rc = belief_check(b, "epi_pf_finish");
+    int rc = shard_check(c, b, "epi_pf_finish");
     if (rc) return rc;
     if (b->phase != PH_WEIGHED) return fail(EPI_ESTATE, "epi_pf_finish: no update in progress");
     HIPCHECK(hipSetDevice(c->device));
@@ -3490,6 +3522,7 @@ static int epi_pf_finish_body(epi_ctx* c, epi_belief* b, uint32_t* flags)
     // owned slots that neither epi_pf_select_local nor epi_pf_import has given an ancestor wait for epi_pf_import_late
     b->unfilled = spans_complement(b->filled, b->n);
     b->filled.clear();
+    b->selected = false;
     b->phase = b->unfilled.empty() ? PH_IDLE : PH_PENDING;
     return EPI_OK;
 }
@@ -3515,7 +3548,7 @@ static int enqueue_sums(epi_ctx* c, epi_belief* b)
 
 int epi_belief_sums(epi_ctx* c, epi_belief* b, int64_t* sums)
 {
-    int rc = belief_check(b, "epi_belief_sums");
+    int rc = shard_check(c, b, "epi_belief_sums");
     if (rc) return rc;
     if (!sums) return fail(EPI_EINVAL, "epi_belief_sums: sums is NULL");
     if (b->phase != PH_IDLE) return fail(EPI_ESTATE, "epi_belief_sums: a phased update is in progress");
@@ -3876,6 +3909,19 @@ static int rccl_load(RcclApi& R)
     return EPI_OK;
 }
 
+// the largest of the shards' local maxima, read where they lie (x[g][0]: shard g's, on its own device)
+__global__ void k_max_of(const double* const* x, int G, double* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double mx = -INFINITY;
+    for (int g = 0; g < G; g++) {           // system scope: another device wrote it, no cache of this one may answer
+        const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(x[g]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double v = __longlong_as_double((long long)bits);
+        mx = v > mx ? v : mx;
+    }
+    *out = mx;
+}
+
 struct epi_mctx {
     int G = 0;
     int64_t n_total = 0;
@@ -3891,6 +3937,9 @@ struct epi_mctx {
     // that were filled locally first, then places the blocks, then steps the rest (epi_pf_predict_part_dev).
     std::vector<hipStream_t> cs;            // per shard: the stream its outgoing copies run on
     std::vector<hipEvent_t> ev_exp;         // per shard: its blocks are packed (main stream)
+    std::vector<hipEvent_t> ev_max;         // per shard: its step has left its maximum log weight in d_x[g][0] (main stream)
+    std::vector<const double**> d_peer;     // per shard, on its device: the G addresses d_x[0 .. G)
+    bool direct_max = false;                // every shard's device can read every other shard's d_x (same device or peer access)
     struct Block { int from, to; int64_t s0, s1; size_t send_off, recv_off; };
     std::vector<Block> late;                // blocks of the last update that are not placed yet
     std::vector<Span> kept;                 // per shard: the columns its own particles filled in the last update
@@ -3924,6 +3973,8 @@ int epi_mctx_destroy(epi_mctx* m)
         (void)hipSetDevice(m->device[g]);
         if (g < (int)m->ev.size() && m->ev[g]) (void)hipEventDestroy(m->ev[g]);
         if (g < (int)m->ev_exp.size() && m->ev_exp[g]) (void)hipEventDestroy(m->ev_exp[g]);
+        if (g < (int)m->ev_max.size() && m->ev_max[g]) (void)hipEventDestroy(m->ev_max[g]);
+        if (g < (int)m->d_peer.size() && m->d_peer[g]) (void)hipFree((void*)m->d_peer[g]);
         if (g < (int)m->cs.size() && m->cs[g]) (void)hipStreamDestroy(m->cs[g]);
         if (g < (int)m->d_x.size() && m->d_x[g]) (void)hipFree(m->d_x[g]);
         if (g < (int)m->d_send.size() && m->d_send[g]) (void)hipFree(m->d_send[g]);
@@ -3953,6 +4004,8 @@ int epi_mctx_create(const int* device_ids, int n_shards, const epi_params* p, in
         m->device.assign(device_ids, device_ids + G);
         m->ctx.assign(G, nullptr); m->b.assign(G, nullptr); m->d_x.assign(G, nullptr); m->d_send.assign(G, nullptr); m->d_recv.assign(G, nullptr);
         m->ev.assign(G, nullptr); m->ev_exp.assign(G, nullptr); m->cs.assign(G, nullptr); m->kept.assign(G, Span(0, 0));
+        m->ev_max.assign(G, nullptr); m->d_peer.assign(G, nullptr);
+        bool direct = true;
         m->start.resize(G + 1);
         for (int g = 0; g <= G; g++) m->start[g] = shard_start(n_total, G, g);
         const int rows = state_rows(p->H, p->D);
@@ -3976,17 +4029,33 @@ int epi_mctx_create(const int* device_ids, int n_shards, const epi_params* p, in
             }
             HIPCHECK(hipEventCreateWithFlags(&m->ev[g], hipEventDisableTiming));
             HIPCHECK(hipEventCreateWithFlags(&m->ev_exp[g], hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&m->ev_max[g], hipEventDisableTiming));
             HIPCHECK(hipStreamCreateWithFlags(&m->cs[g], hipStreamNonBlocking));
             for (int h = 0; h < g; h++) {                       // direct copies between the two devices where the hardware allows
                 if (device_ids[h] == device_ids[g]) continue;
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, device_ids[g], device_ids[h]) == hipSuccess && can) {
-                    (void)hipSetDevice(device_ids[g]); (void)hipDeviceEnablePeerAccess(device_ids[h], 0);
-                    (void)hipSetDevice(device_ids[h]); (void)hipDeviceEnablePeerAccess(device_ids[g], 0);
+                int can = 0, can_back = 0;
+                bool on = false;
+                if (hipDeviceCanAccessPeer(&can, device_ids[g], device_ids[h]) == hipSuccess && can &&
+                    hipDeviceCanAccessPeer(&can_back, device_ids[h], device_ids[g]) == hipSuccess && can_back) {
+                    (void)hipSetDevice(device_ids[g]);
+                    hipError_t e1 = hipDeviceEnablePeerAccess(device_ids[h], 0);
+                    (void)hipSetDevice(device_ids[h]);
+                    hipError_t e2 = hipDeviceEnablePeerAccess(device_ids[g], 0);
                     (void)hipGetLastError();                    // "already enabled" is not an error here
+                    on = (e1 == hipSuccess || e1 == hipErrorPeerAccessAlreadyEnabled) && (e2 == hipSuccess || e2 == hipErrorPeerAccessAlreadyEnabled);
                 }
+                if (!on) direct = false;
             }
         }
+        // where every device reads every other's memory, each shard takes the maximum of the G local maxima itself
+        // (k_max_of); its table of their addresses is filled once, here
+        m->direct_max = direct;
+        if (direct)
+            for (int g = 0; g < G; g++) {
+                HIPCHECK(hipSetDevice(device_ids[g]));
+                HIPCHECK(hipMalloc((void**)&m->d_peer[g], sizeof(double*) * (size_t)G));
+                HIPCHECK(hipMemcpy((void*)m->d_peer[g], m->d_x.data(), sizeof(double*) * (size_t)G, hipMemcpyHostToDevice));
+            }
         HIPCHECK(hipHostMalloc((void**)&m->h_x, sizeof(double) * 8 * (size_t)G, hipHostMallocDefault));
         if (m->rccl) {
             int rc = rccl_load(m->api);
@@ -4126,11 +4195,20 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
             }
             if (rc) return rc;
         }
-        // 2. the global maximum
+        // 2. the global maximum: over RCCL; else read by every shard from the other shards' device memory once their
+        // steps are through (no host wait); else (devices without access to each other) through host memory
         if (m->rccl) {
             NCCLCHECK(m, m->api.GroupStart());
             for (int g = 0; g < G; g++) NCCLCHECK(m, m->api.AllReduce(m->d_x[g], m->d_x[g] + 1, 1, ncclDouble, ncclMax, m->comm[g], st(g)));
             NCCLCHECK(m, m->api.GroupEnd());
+        } else if (m->direct_max && !(g_node_exchange & 2)) {
+            for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipEventRecord(m->ev_max[g], st(g))); }
+            for (int g = 0; g < G; g++) {
+                HIPCHECK(dev(g));
+                for (int h = 0; h < G; h++) if (h != g) HIPCHECK(hipStreamWaitEvent(st(g), m->ev_max[h], 0));
+                k_max_of<<<1, 64, 0, st(g)>>>(m->d_peer[g], G, m->d_x[g] + 1);
+                HIPCHECK(hipGetLastError());
+            }
         } else {
             for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipMemcpyAsync(m->h_x + 8 * g, m->d_x[g], sizeof(double), hipMemcpyDeviceToHost, st(g))); }
             for (int g = 0; g < G; g++) { HIPCHECK(dev(g)); HIPCHECK(hipStreamSynchronize(st(g))); }
@@ -4215,7 +4293,7 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
             if (in_flight) continue;
             const size_t bytes = sizeof(int32_t) * (size_t)rows * (size_t)(k.s1 - k.s0);
             HIPCHECK(dev(k.from));
-            if (m->device[k.from] == m->device[k.to])
+            if (m->device[k.from] == m->device[k.to] && !(g_node_exchange & 1))
                 HIPCHECK(hipMemcpyAsync(m->d_recv[k.to] + k.recv_off, src, bytes, hipMemcpyDeviceToDevice, st(k.from)));
             else
                 HIPCHECK(hipMemcpyPeerAsync(m->d_recv[k.to] + k.recv_off, m->device[k.to], src, m->device[k.from], bytes, st(k.from)));
@@ -4230,7 +4308,7 @@ int epi_mpf_update(epi_mctx* m, double a, int64_t o, uint64_t seed, uint32_t ste
             for (const Block& k : blocks) {
                 const size_t bytes = sizeof(int32_t) * (size_t)rows * (size_t)(k.s1 - k.s0);
                 HIPCHECK(dev(k.from));
-                if (m->device[k.from] == m->device[k.to])
+                if (m->device[k.from] == m->device[k.to] && !(g_node_exchange & 1))
                     HIPCHECK(hipMemcpyAsync(m->d_recv[k.to] + k.recv_off, m->d_send[k.from] + k.send_off, bytes, hipMemcpyDeviceToDevice, m->cs[k.from]));
                 else
                     HIPCHECK(hipMemcpyPeerAsync(m->d_recv[k.to] + k.recv_off, m->device[k.to], m->d_send[k.from] + k.send_off, m->device[k.from], bytes, m->cs[k.from]));

@@ -210,7 +210,7 @@ int epi_pf_update(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t see
  *                       output-slot range [lo[g], lo[g+1]) whose ancestors live
  *                       in shard g (host arithmetic, identical on every rank).
  *   4. epi_pf_select_local : ancestors for the part of that range this shard
- *                       also owns (no data movement).  Called before the first
+ *                       also owns (no data movement); at most once per update.  Called before the first
  *                       export of an update it also leaves the cumulative weights
  *                       that the exports search (one pass instead of two; any
  *                       order of the calls of this step gives the same result);
@@ -259,14 +259,19 @@ int epi_pf_import_late(epi_ctx *ctx, epi_belief *b, int64_t slot_begin, int64_t 
 /* An epi_mctx is ONE population of n_total particles sharded by index over n_shards devices (shard g holds global
  * slots [n_total g / G, n_total (g + 1) / G)), driven by the calling host thread: what a Julia host needs to run
  * update(BootstrapFilter(pomdp, n), b, a, o) (call sites src/POMDPsInterface.jl:56, src/MPC.jl:393) on the eight
- * GPUs of a node through plain ccall, with no process per GPU and no message passing of its own.  Results are
- * bit-identical for every number of shards, and equal to epi_pf_update on one device.
+ * GPUs of a node through plain ccall, with no process per GPU and no message passing of its own.  The particles, the
+ * log-likelihood and the flags are bit-identical for every number of shards and equal to epi_pf_update's on one device
+ * (integer weight totals and a maximum: no summation order enters); the effective sample size divides by a binary64
+ * sum of squares whose order of addition follows the sharding, so it agrees to rounding (1e-12 relative), not bit for bit.
  *   device_ids  one HIP device per shard; a device may be named more than once (several shards share it: how this is
  *               tested on a machine with one GPU), unless use_rccl is set
- *   use_rccl    0: the two small exchanges of an update (maximum log weight; four doubles per shard) go through
- *               page-locked host memory; 1: through RCCL (ncclAllReduce MAX, ncclAllGather, one group call each, over
- *               xGMI), for which librccl.so is loaded at run time.  Particles that change shard always go device to
- *               device (hipMemcpyPeerAsync), in packed blocks, pairwise -- no ring.
+ *   use_rccl    0: of the two small exchanges of an update, the maximum log weight is read by every shard from the other
+ *               shards' device memory (devices with access to each other, or shards of one device; through page-locked
+ *               host memory and one more host wait where the devices have no such access) and the four doubles per
+ *               shard of the weight totals go through page-locked host memory, the update's one host wait;
+ *               1: both through RCCL (ncclAllReduce MAX, ncclAllGather, one group call each, over xGMI), for which
+ *               librccl.so is loaded at run time.  Particles that change shard always go device to device
+ *               (hipMemcpyPeerAsync), in packed blocks, pairwise -- no ring.
  * Memory per shard: the belief with a halo of n_local columns plus one send and one receive buffer of n_local
  * particles. */
 typedef struct epi_mctx epi_mctx;
@@ -375,14 +380,17 @@ int epi_closed_loop_days(epi_ctx *ctx, epi_belief *truth, epi_belief *b, int nda
                          int64_t *sums, int64_t *quant);
 
 /* ---- for callers that cannot allocate ------------------------------------------- */
-/* epi_pf_update for hosts that must not call hipMalloc while they run (code under HIP graph capture, tight
- * serving loops, harnesses that forbid it).  No counterpart in the reference.  Same arguments, same results bit
+/* epi_pf_update for hosts that must not call hipMalloc while they run (tight serving loops, harnesses that forbid
+ * allocation).  No counterpart in the reference.  The call is synchronous like epi_pf_update (it waits for the
+ * stream and reads the diagnostics back), so it cannot run under HIP graph capture.  Same arguments, same results bit
  * for bit; the scratch of the update (scalars, per-tile weight totals, the list of long child ranges: 1.4 MB)
  * lives in a file-scope device array of the library instead of buffers owned by the belief, so the call makes no
  * hipMalloc / hipFree / hipEventCreate of any kind; results come back through the context's page-locked buffer.
  * Limit: at most 2^27 = 134 217 728 particles (EPI_ERANGE beyond).  Every device holds one such array for the life of
  * the process and every call on a device uses it: calls that overlap in time on one device (two contexts, two
- * threads) race; calls in sequence do not.  The belief must be a whole population (not a shard). */
+ * threads) race; calls in sequence do not (a call leaves nothing queued on the array when it returns).  The belief
+ * must be a whole population (not a shard).  epi_pf_collect does not apply to this call: it reads the scalars of the
+ * belief's own last epi_pf_update / epi_pf_update_async, which this call does not touch. */
 int epi_pf_update_noalloc(epi_ctx *ctx, epi_belief *b, double a, int64_t o, uint64_t seed, uint32_t step,
                           double *loglik, double *ess, uint32_t *flags);
 

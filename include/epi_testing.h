@@ -37,6 +37,13 @@ int epi_debug_step_impl(int cooperative);
  * as accepted, settled as rejected, left open, settled differently from the defining test (must be 0).  No counterpart
  * in the reference. */
 int epi_debug_btrs_quick(epi_ctx *ctx, uint64_t seed, int32_t n_lo, uint32_t n_span, double pp, int blocks, uint64_t *out5);
+/* epi_mpf_update moves particle blocks between shards with hipMemcpyAsync when both shards share a device and with
+ * hipMemcpyPeerAsync otherwise, and finds the global maximum log weight by letting every shard read the other shards'
+ * device memory when the devices have access to each other, through host memory otherwise.  A box with one GPU only
+ * ever takes the first branch of each.  mode bit 0: peer copies even between shards of one device; bit 1: the maximum
+ * through host memory even where devices see each other.  Results are identical in every mode.  Testing aid,
+ * process-wide.  No counterpart in the reference. */
+int epi_debug_node_exchange(int mode);
 
 #ifdef __cplusplus
 }

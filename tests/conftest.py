@@ -71,5 +71,6 @@ def testing_lib():
     finally:
         _lib._lib.epi_debug_step_impl(1)
         _lib._lib.epi_debug_screen(1)
+        _lib._lib.epi_debug_node_exchange(0)
         interface._contexts.clear()
         _lib._lib = saved

@@ -53,9 +53,38 @@ def test_bench_two_ranks_on_the_box_report_their_world_size():
     # two ranks share the box's one GPU and exchange through gloo (RCCL wants one device per rank): the whole sharded
     # bench path with a process group of two, started by bench.py itself
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--particles", "20000", "--steps", "2", "--warmup", "1", "--no-cpu"],
-                       env=_env(EPI_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                       env=_env(EPI_BENCH_BACKEND="gloo", EPI_BENCH_NODE_DEVICES="0,0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     res = _json_line(p.stdout)
     assert res["n_gpus"] == 2 and res["world_size"] == 2 and res["backend"] == "gloo"
     assert res["config"]["particles"] == 20000 and res["value"] > 0
     assert res["diagnostics"]["flags"] == 0
+    # the same update through epi_mctx_create + epi_mpf_update, timed in a child process of rank 0: two shards on the one
+    # device here (no RCCL between shards of one device), the same population, so the same diagnostics
+    nf = res["node_filter"]
+    assert "error" not in nf, nf
+    assert set(nf) >= {"ms_per_step", "value", "moved", "overlapped_updates", "rccl_devices", "shards", "devices", "diagnostics"}
+    assert nf["shards"] == 2 and nf["devices"] == [0, 0] and nf["rccl_devices"] == 0
+    assert nf["ms_per_step"] > 0 and nf["value"] > 0 and nf["moved"] >= 0 and 0 <= nf["overlapped_updates"] <= 2
+    assert nf["diagnostics"]["flags"] == 0
+    assert abs(nf["diagnostics"]["loglik"] - res["diagnostics"]["loglik"]) <= 1e-9 * abs(res["diagnostics"]["loglik"])
+    assert abs(nf["diagnostics"]["ess"] - res["diagnostics"]["ess"]) <= 1e-9 * res["diagnostics"]["ess"]
+
+
+def test_a_failing_node_filter_child_is_reported_inside_the_block():
+    # no device here (or none numbered 97): the child fails, the block says so, nothing is raised
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = os.environ.get("EPI_BENCH_NODE_DEVICES")
+    os.environ["EPI_BENCH_NODE_DEVICES"] = "97,98"
+    try:
+        nf = bench.node_filter_block(argparse.Namespace(gpus=2, particles=1000, steps=1, warmup=0))
+    finally:
+        if saved is None:
+            del os.environ["EPI_BENCH_NODE_DEVICES"]
+        else:
+            os.environ["EPI_BENCH_NODE_DEVICES"] = saved
+    assert "error" in nf and "ms_per_step" not in nf

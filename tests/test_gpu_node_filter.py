@@ -88,11 +88,7 @@ def test_node_filter_updates_back_to_back(delay, G, overlap):
     f.close()
 
 
-def test_node_filter_random_shapes_and_observations():
-    """Small random populations over 1 to 8 shards (some shards smaller than a workgroup), five updates each with
-    observations from typical to impossible and now and then no testing at all (every weight zero), nothing read in
-    between: collapses onto one shard, exchanges left in flight and updates that keep every particle follow each other in
-    every order.  Posterior and diagnostics equal the oracle's."""
+def _random_shapes_and_observations():
     rng = np.random.default_rng(20261111)
     pomdp = em.make_pomdp(LOD=5, test_delay=1)
     orc = pyoracle.Oracle(pomdp.to_c())
@@ -118,6 +114,27 @@ def test_node_filter_random_shapes_and_observations():
         for name, x, y in zip("SIRT", f.download(), st):
             assert (x == y).all(), (case, name)
         f.close()
+
+
+def test_node_filter_random_shapes_and_observations():
+    """Small random populations over 1 to 8 shards (some shards smaller than a workgroup), five updates each with
+    observations from typical to impossible and now and then no testing at all (every weight zero), nothing read in
+    between: collapses onto one shard, exchanges left in flight and updates that keep every particle follow each other in
+    every order.  Posterior and diagnostics equal the oracle's."""
+    _random_shapes_and_observations()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_node_filter_random_shapes_through_the_branches_several_devices_take(testing_lib, mode):
+    """The same cases with the shards of the one device treated as if they lay on different devices: particle blocks
+    go through hipMemcpyPeerAsync (mode bit 0; receivers wait for the senders' events as always), and the global
+    maximum goes through host memory as between devices without access to each other (bit 1) instead of being read from
+    the other shards' memory."""
+    assert testing_lib.epi_debug_node_exchange(mode) == 0
+    try:
+        _random_shapes_and_observations()
+    finally:
+        testing_lib.epi_debug_node_exchange(0)
 
 
 def test_node_filter_all_weights_zero_keeps_the_particles():

@@ -903,6 +903,29 @@ def test_suminf_quantiles_and_belief_summaries():
 
 
 # ---------------------------------------------------------------------------
+# run-to-run reproducibility (workgroups hand draws to each other through LDS queues: a missing barrier shows up as a
+# handful of particles in a hundred thousand that differ from one launch to the next)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("delay,H", [(0, 14), (1, 14), (0, 21)])
+def test_step_and_update_repeat_bit_for_bit(delay, H):
+    pomdp = em.make_pomdp(LOD=5, test_delay=delay) if H == 14 else em.make_pomdp(LOD=5, test_delay=delay, horizon=H)
+    n = 300_007
+    first = None
+    for rep in range(5):
+        b = em.initialbelief(pomdp, n, seed=11)
+        o, r, _ = em.step_batch(b, 0.2, seed=77, step=3)
+        upd = em.BootstrapFilter(pomdp, n, seed=5, step=4)
+        em.update(upd, b, em.Action(0.3), int(np.median(o)))
+        got = (o.copy(), r.copy()) + tuple(b.download()) + (np.array([upd.last_loglik, upd.last_ess]),)
+        b.close()
+        if first is None:
+            first = got
+        else:
+            for name, x, y in zip(("o", "r", "S", "I", "R", "T", "diag"), first, got):
+                assert (x == y).all(), (name, rep, int((x != y).sum()))
+
+
+# ---------------------------------------------------------------------------
 # error behaviour of the C ABI
 # ---------------------------------------------------------------------------
 def test_error_codes_and_messages():
@@ -936,6 +959,19 @@ def test_error_codes_and_messages():
     check(lib.epi_pf_weigh(ctx.handle, b.handle, v.value, C.byref(w), C.byref(sq), None))
     assert code(lambda: lib.epi_pf_select_local(ctx.handle, b.handle, 1, 0, C.byref(w), 1, 0, 0, n + 1)) == -1   # slots not owned
     check(lib.epi_pf_select_local(ctx.handle, b.handle, 1, 0, C.byref(w), 1, 0, 0, n))
+    assert code(lambda: lib.epi_pf_select_local(ctx.handle, b.handle, 1, 0, C.byref(w), 1, 0, 0, n)) == -5       # once per update
+    # every phased call wants the belief's own context: none, or another shard's, is refused the same way everywhere
+    other = C.c_void_p()
+    check(lib.epi_ctx_create(0, C.byref(other)))
+    buf = C.create_string_buffer(64)
+    for wrong in (None, other):
+        assert code(lambda: lib.epi_pf_export(wrong, b.handle, 1, 0, C.byref(w), 1, 0, 0, 1, buf)) == -1
+        assert code(lambda: lib.epi_pf_import(wrong, b.handle, 0, 1, buf)) == -1
+        assert code(lambda: lib.epi_pf_finish(wrong, b.handle, None)) == -1
+        assert code(lambda: lib.epi_pf_weigh(wrong, b.handle, 0.0, C.byref(w), C.byref(sq), None)) == -1
+        assert code(lambda: lib.epi_pf_weigh_dev(wrong, b.handle, buf, buf)) == -1
+        assert code(lambda: lib.epi_belief_sums(wrong, b.handle, C.cast(buf, C.POINTER(C.c_int64)))) == -1
+    check(lib.epi_ctx_destroy(other))
     check(lib.epi_pf_finish(ctx.handle, b.handle, None))
     # states that violate the stored layout (Tests row D+1 / column 1 must be zero) are rejected on upload
     S, I, R, T = b.download()
