@@ -590,9 +590,20 @@ constexpr int COOP_WAVES = EPI_COOP_WAVES;   // waves per SIMD the register allo
 // are padded to whole workgroups and the surplus threads of the last one step copies of the last particle into the
 // padding (their optional outputs and flags are dropped; their log weight equals the last particle's, so the maximum
 // is unchanged).
-template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true, bool FULL = false>
+// NC > 1 (wide states): a particle is stepped by NC threads of the workgroup, each owning every NC-th pair of
+// infection terms (terms 2j and 2j+1 share a block of variates) and the age bins that seed them, so that a workgroup
+// holds 256 / NC particles and its LDS footprint -- 8 H bytes per particle -- stays that of a narrow state.  Thread tid
+// steps particle tid mod (256 / NC) with share tid / (256 / NC) (one share per wave or pair of waves: bin indices stay
+// wave-uniform; dealing the pairs out in turn gives every wave young and old ages alike, whose draws differ in cost).
+// Draws are addressed by (slot, bin), so which thread makes them is immaterial; the integer sums over bins are
+// combined through LDS, and everything whose order of evaluation enters the result (the observation moments, the
+// infection sum) is taken in bin order by the thread of share 0.
+template <bool WEIGH, bool DELAY, int HC = 0, bool SCREEN = true, bool FULL = false, int NC = 1>
 __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A, const DevParams* __restrict__ Dp)
 {
+    static_assert(NC == 1 || (HC == 0 && !FULL), "chunked particles: run-time H, bounds-checked");
+    static_assert(NC == 1 || NC == 2 || NC == 4, "one share per whole number of waves");
+    constexpr int PW = CTPB / NC;                                                  // particles per workgroup
     const epi_params& P = Dp->P;
     // Arguments needed only at the end of the kernel are re-read from the kernel-argument segment there (scalar
     // loads) instead of occupying scalar registers across the sampler phases, which are short of them.
@@ -600,20 +611,31 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     const KernArgs Ak = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     extern __shared__ __align__(16) unsigned char smem[];
     const int H = HC ? HC : P.H, D = DELAY ? P.D : 0;
-    int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][CTPB]: (I_i, tested_i) -> (sympt_i, pos_i)
+    int2* slots = reinterpret_cast<int2*>(smem);                                   // [H][PW]: (I_i, tested_i) -> (sympt_i, pos_i)
     int* slot_words = reinterpret_cast<int*>(smem);
-    double* gslots = reinterpret_cast<double*>(smem);                              // [H][CTPB]: gamma term of the bin's survivors
-    unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * CTPB * 8);
+    double* gslots = reinterpret_cast<double*>(smem);                              // [H][PW]: gamma term of the bin's survivors
+    unsigned short* q0 = reinterpret_cast<unsigned short*>(smem + (size_t)H * PW * 8);
     unsigned short* q1 = q0 + QCAP;
     unsigned int* qn = reinterpret_cast<unsigned int*>(q1 + QCAP1);                 // qn[0..2]: entry counts, rotating (+ 1 pad)
     unsigned int* qw = qn + 4;                                                     // [CTPB/64]: entries of each wave's segment of the first queue
     unsigned long long* s_max = reinterpret_cast<unsigned long long*>(qw + CTPB / 64);   // [CTPB/64]
     ZigEntry* ztab = reinterpret_cast<ZigEntry*>(s_max + CTPB / 64);               // [ZIG_N]: strips of the normal generator
     CoopRec* crec = reinterpret_cast<CoopRec*>(ztab + ZIG_N);                       // [2][H]: per-(draw, bin) constants for the retry rounds
+    int* acc = reinterpret_cast<int*>(crec + 2 * H);                               // NC > 1, [4][PW]: the chunks' shares of R, o, sum(I') and sum(I)
 
     const int tid = threadIdx.x;
-    const int64_t base = ((int64_t)xcd_tile() + A.block0) * CTPB;
-    const int64_t m = base + tid;
+    const int lp = NC == 1 ? tid : (tid & (PW - 1));                               // the thread's particle within the workgroup
+    const int ch = NC == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid / PW);         // its share (wave-uniform)
+    // its terms, in order: term_of(0 .. nown); term `it` is seeded by bin (it == 0 ? H-1 : it-1) (simulate.jl:145)
+    const int J = (H + 1) >> 1;                                                    // pairs of terms
+    const int npair = NC == 1 ? J : (ch < J ? (J - ch + NC - 1) / NC : 0);
+    const int nown = NC == 1 ? H : 2 * npair - (((H & 1) && npair > 0 && (J - 1) % NC == ch) ? 1 : 0);
+    auto term_of = [&](int k) -> int { return NC == 1 ? k : 2 * (ch + (k >> 1) * NC) + (k & 1); };
+    auto bin_of = [&](int k) -> int { const int it = term_of(k); return it == 0 ? H - 1 : it - 1; };
+    auto owns = [&](int i) -> bool { return NC == 1 || (((i + 1 == H ? 0 : i + 1) >> 1) % NC) == ch; };
+    const bool lead = NC == 1 || ch == 0;                                          // the thread that holds S and R and closes the step
+    const int64_t base = ((int64_t)xcd_tile() + A.block0 * NC) * PW;
+    const int64_t m = base + lp;
     const bool active = FULL ? true : m < A.n;
     const int64_t mc = FULL ? (m < A.n ? m : A.n - 1) : m;                         // the particle this thread reads
     const int64_t src = active ? (A.anc ? (int64_t)A.anc[mc] : mc) : 0;
@@ -633,8 +655,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     const int64_t is = (int64_t)is_u, os = (int64_t)os_u;
     // state rows: one coalesced 4-byte access per lane and row
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
-    auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[tid], v); };
+    auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[lp], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
+    if constexpr (NC > 1) for (int r = tid; r < 4 * PW; r += CTPB) acc[r] = 0;
     for (int r = tid; r < ZIG_N; r += CTPB) ztab[r] = Dp->zig.e[r];
     for (int r = tid; r < 2 * H; r += CTPB) {
         const BinConsts& bc = Dp->bc[r >= H][r >= H ? r - H : r];
@@ -653,22 +676,30 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 
     // ---- A: stage the bins, observation moments -----------------------------------
     if (active) {
-        S = ld_in(0); R = ld_in(1); R_pre = R;
+        if (lead) { S = ld_in(0); R = ld_in(1); R_pre = R; }
         double tm = 0.0, tv = 0.0;
-        int32_t I_next = ld_in(2);                                                 // loads run one bin ahead of their use
+        // the observation moments are sums in bin order: with chunks, the lead thread visits every bin for them
+        // (re-reading the other chunks' rows, which the cache holds) and stages only its own
+        const bool moments = WEIGH && lead;
+        const bool every = NC == 1 || moments;                                     // all bins, in order
+        const int na = every ? H : nown;
+        int32_t I_next = na > 0 ? ld_in(2 + (every ? 0 : bin_of(0))) : 0;          // loads run one bin ahead of their use
 #pragma unroll 1
-        for (int i = 0; i < H; i++) {
+        for (int q = 0; q < na; q++) {
+            const int i = every ? q : bin_of(q);
             const int32_t Ii = I_next;
-            if (i + 1 < H) I_next = ld_in(3 + i);
+            if (q + 1 < na) I_next = ld_in(2 + (every ? q + 1 : bin_of(q + 1)));
             int32_t already = 0;
             if (D > 0 && i >= 1)
                 for (int r = 0; r < D; r++) already += ld_in(tests_row(H, r, i));
             const double ntf = __builtin_floor((double)(Ii - already) * a);        // simulate.jl:78
             const int32_t nt = (int32_t)ntf;
             if (nt < 0) flags |= EPI_F_NEG_NT;
-            slots[i * CTPB + tid] = make_int2(Ii, nt);
-            suminf_pre += Ii;
-            if constexpr (WEIGH) {
+            if (owns(i)) {
+                slots[i * PW + lp] = make_int2(Ii, nt);
+                suminf_pre += Ii;
+            }
+            if (WEIGH && moments) {
                 const double pi = P.p[i];
                 tm += ntf * pi;                                                    // POMDPsInterface.jl:19
                 if (pi > 0.0 && pi < 1.0) {                                        // else std = 0 exactly: nothing to add
@@ -679,9 +710,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 }
             }
         }
-        if constexpr (WEIGH) {
+        if (WEIGH && moments) {
             const double lw = log_weight(tm, tv, Ak->o_dev ? (double)*Ak->o_dev : Ak->o);
-            EPI_STREAM_STORE(&(Ak->lw + base)[tid], lw);
+            EPI_STREAM_STORE(&(Ak->lw + base)[lp], lw);
             code = order_code(lw);
         }
     }
@@ -700,9 +731,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     const int lane = tid & 63;
     unsigned short* const qseg = q0 + (unsigned int)(tid >> 6) * QSEG;
 #pragma unroll 1
-    for (int i = 0; i < H; i++) {
+    for (int kb = 0; kb < nown; kb++) {
+        const int i = NC == 1 ? kb : bin_of(kb);
         if (active) {
-            int2 nn = slots[i * CTPB + tid];
+            int2 nn = slots[i * PW + lp];
             uint32_t w[4];
             rng_block(g, K_BINOM0, (uint32_t)i, 0, w);
             // both draws of the bin as straight code: no selects on j, and the scheduler can overlap the two
@@ -738,14 +770,14 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                     const unsigned int pos = wcount + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
                     if (st != BTRS_ACCEPT) {
                         // bit 15: attempt 0 is settled (rejected), the draw goes on with attempt 1
-                        if (pos < QSEG) qseg[pos] = (unsigned short)(tid | (i << 8) | (j << 14) | ((st == BTRS_REJECT) << 15));
+                        if (pos < QSEG) qseg[pos] = (unsigned short)(lp | (i << 8) | (j << 14) | ((st == BTRS_REJECT) << 15));
                         else if (i < 32) over0 |= 1ULL << (2 * i + j);
                         else over1 |= 1ULL << (2 * (i - 32) + j);
                     }
                     wcount += (unsigned int)__popcll(mask);
                 }
             }
-            slots[i * CTPB + tid] = nn;
+            slots[i * PW + lp] = nn;
         }
     }
     if (lane == 0) qw[tid >> 6] = wcount < QSEG ? wcount : QSEG;
@@ -755,9 +787,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             const int bit = __ffsll((long long)om) - 1;
             om &= om - 1ULL;
             const int i = (bit >> 1) + 32 * half, j = bit & 1;
-            const int32_t n = slot_words[(i * CTPB + tid) * 2 + j];
+            const int32_t n = slot_words[(i * PW + lp) * 2 + j];
             const int32_t k = btrs_from0(n, Dp->bc[j][i].btrs(), Dp->lf, screen, g, j, (uint32_t)i);
-            slot_words[(i * CTPB + tid) * 2 + j] = Dp->flip[j][i] ? n - k : k;
+            slot_words[(i * PW + lp) * 2 + j] = Dp->flip[j][i] ? n - k : k;
         }
     }
 
@@ -812,12 +844,12 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 if (round == 1u && (entry >> 15)) atomicAdd(&g_phase[15], 1ULL);
 #endif
                 const uint32_t att = round - 1u + (uint32_t)(entry >> 15);
-                const int32_t n = slot_words[(i * CTPB + t) * 2 + j];
+                const int32_t n = slot_words[(i * PW + t) * 2 + j];
                 const CoopRec rec = crec[j * H + i];
                 const BtrsBin B{rec.ppx, rec.pq, rec.a0x2, rec.lpq};
                 const bool flip = rec.flip != 0;                                   // a queued draw is a rejection draw
 #if EPI_X_CUT == 1
-                slot_words[(i * CTPB + t) * 2 + j] = flip ? n : 0; continue;
+                slot_words[(i * PW + t) * 2 + j] = flip ? n : 0; continue;
 #endif
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 // attempt 0 takes its half of the bin's first block, attempt a >= 1 half (a - 1) & 1 of block (a - 1) / 2 of the draw's own stream
@@ -828,23 +860,23 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 rng_block(gt, kind, (uint32_t)i, first ? 0u : (att - 1u) >> 1, w);
                 const uint32_t wa = hi ? w[2] : w[0], wb = hi ? w[3] : w[1];
 #if EPI_X_CUT == 2
-                slot_words[(i * CTPB + t) * 2 + j] = (wa ^ wb) & 1; continue;
+                slot_words[(i * PW + t) * 2 + j] = (wa ^ wb) & 1; continue;
 #endif
                 const BtrsConsts C = btrs_consts(n, B);
                 int32_t k;
 #if EPI_X_CUT == 3
-                slot_words[(i * CTPB + t) * 2 + j] = (int32_t)(C.spq + C.cfr) + C.ci + C.m + ((wa ^ wb) & 1); continue;
+                slot_words[(i * PW + t) * 2 + j] = (int32_t)(C.spq + C.cfr) + C.ci + C.m + ((wa ^ wb) & 1); continue;
 #endif
                 if (n < lf_n) k = btrs_attempt_tab(C, B.lpq, lf_t, screen, wa, wb);
                 else k = btrs_attempt_far(C, B.lpq, LfTable{lf_t, lf_n}, screen, wa, wb);
 #if EPI_X_CUT == 4
-                slot_words[(i * CTPB + t) * 2 + j] = k < 0 ? 0 : k; continue;
+                slot_words[(i * PW + t) * 2 + j] = k < 0 ? 0 : k; continue;
 #endif
                 const bool fail = k < 0;
                 // the first rounds hand rejected draws on; after them (and when the queue is full) a draw is finished by the thread that holds it
                 const bool pushed = round < COOP_BINOM_ROUNDS && q_push(fail, entry, qnext, &qn[nxt], qcap_next);
                 if (fail && !pushed) k = btrs_finish_thread(C, B.lpq, LfTable{lf_t, lf_n}, screen, gt, j ? K_POS : K_SYMPT, (uint32_t)i, att + 1u);
-                if (k >= 0) slot_words[(i * CTPB + t) * 2 + j] = flip ? n - k : k;
+                if (k >= 0) slot_words[(i * PW + t) * 2 + j] = flip ? n - k : k;
             }
             cur = nxt;
         }
@@ -860,21 +892,25 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     int32_t sum_inf = 0;
     unsigned long long g_over = 0ULL;  // terms that found the queue full
     uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
-    int32_t I_next = active ? ld_in(1 + H) : 0;                                    // bin H-1; loads run one bin ahead
-    int2 sp_next = slots[(H - 1) * CTPB + tid];                                    // so does the read of the bin's slot
+    const int nterm = nown;
+    const int i_first = nterm > 0 ? bin_of(0) : 0;
+    int32_t I_next = (active && nterm > 0) ? ld_in(2 + i_first) : 0;               // loads run one bin ahead
+    int2 sp_next = slots[i_first * PW + lp];                                       // so does the read of the bin's slot
 #pragma unroll 1
-    for (int it = 0; it < H; it++) {
+    for (int k = 0; k < nterm; k++) {
+        const int it = term_of(k);
         const int i = it == 0 ? H - 1 : it - 1;
+        const int i_next = NC == 1 ? it : term_of(k + 1) - 1;                      // bin of the next iteration (never bin H-1)
         bool gfail = false;
         // the term's Gamma parameters (wave-uniform) are requested at the top of the iteration, not at their first use
         const double k_it = P.k[it], theta_it = P.theta[it];
         asm volatile("" :: "s"(k_it), "s"(theta_it));
         if (active) {
             const int2 sp = sp_next;
-            if (it + 1 < H) sp_next = slots[it * CTPB + tid];                      // bin of iteration it+1 (another slot than this bin's)
+            if (k + 1 < nterm) sp_next = slots[i_next * PW + lp];                  // bin of the next iteration (another slot than this bin's)
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
-            if (it + 1 < H) I_next = ld_in(2 + it);                                // bin of iteration it+1
+            if (k + 1 < nterm) I_next = ld_in(2 + i_next);                         // bin of the next iteration
             double pr = div_unscaled((double)sympt, (double)Ii);                   // simulate.jl:104
             if (pr != pr) pr = 0.0;                                                // simulate.jl:105
             const double om = 1.0 - pr;
@@ -899,9 +935,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 wz = w[0]; z_odd = w[1]; wu = w[2]; w_odd = w[3];
             }
 #ifdef EPI_X_SKIP_G
-            if (true) gslots[i * CTPB + tid] = shape;
+            if (true) gslots[i * PW + lp] = shape;
 #else
-            if (gamma_is_zero(shape)) gslots[i * CTPB + tid] = 0.0;
+            if (gamma_is_zero(shape)) gslots[i * PW + lp] = 0.0;
 #endif
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
@@ -909,25 +945,35 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 double v;
                 const bool inside = zig_fast(wz, ztab[wz & 255u], xf);
                 // (a shape below 1 needs the boost's extra uniform: left to the rounds, which are not this loop's straight code)
-                if (gamma_fast(G, xf, wu, v) && inside && !G.boost) gslots[i * CTPB + tid] = (G.d * v) * theta_it;
+                if (gamma_fast(G, xf, wu, v) && inside && !G.boost) gslots[i * PW + lp] = (G.d * v) * theta_it;
                 else {
 #ifdef EPI_X_SKIP_E
-                    gslots[i * CTPB + tid] = 0.0;
+                    gslots[i * PW + lp] = 0.0;
 #else
-                    slots[i * CTPB + tid] = make_int2(Ii, 0); gfail = true;
+                    slots[i * PW + lp] = make_int2(Ii, 0); gfail = true;
 #endif
                 }
             }
         }
-        const bool gpushed = q_push(gfail, (unsigned short)(tid | (it << 8)), q0, &qn[spare], QCAP);
+        const bool gpushed = q_push(gfail, (unsigned short)(lp | (it << 8)), q0, &qn[spare], QCAP);
         if (gfail && !gpushed) g_over |= 1ULL << it;                               // queue full: finished after the loop
     }
     while (g_over) {
         const int it = __ffsll((long long)g_over) - 1;
         g_over &= g_over - 1ULL;
         const int i = it == 0 ? H - 1 : it - 1;
-        const int32_t Ii = slots[i * CTPB + tid].x;
-        gslots[i * CTPB + tid] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, g, (uint32_t)it, screen);
+        const int32_t Ii = slots[i * PW + lp].x;
+        gslots[i * PW + lp] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, g, (uint32_t)it, screen);
+    }
+
+    // the other chunks' shares of the particle's integer sums (order is immaterial), ahead of the barriers of phase E
+    if constexpr (NC > 1) {
+        if (active && !lead) {
+            if (R) atomicAdd(&acc[lp], R);
+            if (o_sum) atomicAdd(&acc[PW + lp], o_sum);
+            if (sum_inf) atomicAdd(&acc[2 * PW + lp], sum_inf);
+            if (suminf_pre) atomicAdd(&acc[3 * PW + lp], suminf_pre);
+        }
     }
 
     // ---- E: gamma rounds (round r runs attempt r - 1 in full) ----------------------------------------------------
@@ -952,7 +998,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 const unsigned short entry = q[e];
                 const int t = entry & 255, it = entry >> 8;
                 const int i = it == 0 ? H - 1 : it - 1;
-                const int32_t Ii = slots[i * CTPB + t].x;
+                const int32_t Ii = slots[i * PW + t].x;
                 const GammaConsts G = gamma_consts(P.k[it] * (double)Ii, screen);
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 uint32_t wz, wu;
@@ -963,8 +1009,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 double v;
                 const bool ok = gamma_attempt(G, xf, wu, v);
                 const bool pushed = round < COOP_GAMMA_ROUNDS && q_push(!ok, entry, qnext, &qn[nxt], qcap_next);   // after the cooperative rounds: finished by this thread
-                if (ok) gslots[i * CTPB + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
-                else if (!pushed) gslots[i * CTPB + t] = gamma_finish_from(G, P.theta[it], &Dp->zig, gt, (uint32_t)it, att + 1u);
+                if (ok) gslots[i * PW + t] = gamma_finish(G, v, P.theta[it], gt, (uint32_t)it);
+                else if (!pushed) gslots[i * PW + t] = gamma_finish_from(G, P.theta[it], &Dp->zig, gt, (uint32_t)it, att + 1u);
             }
             cur = nxt;
         }
@@ -973,10 +1019,11 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 
     EPI_STAMP(4);
     // ---- F: infection sum in bin order, new infections, outputs --------------------------------
-    if (active) {
+    if (active && lead) {
+        if constexpr (NC > 1) { R += acc[lp]; o_sum += acc[PW + lp]; sum_inf += acc[2 * PW + lp]; suminf_pre += acc[3 * PW + lp]; }
         double infsum = 0.0;
 #pragma unroll 1
-        for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * CTPB + tid];   // simulate.jl:38-41
+        for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * PW + lp];   // simulate.jl:38-41
         const int64_t denom = P.N - (int64_t)R;
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
@@ -1018,7 +1065,11 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     EPI_STAMP(5);
 }
 
-static size_t coop_lds_bytes(int H) { return (size_t)H * CTPB * 8 + (QCAP + QCAP1) * sizeof(unsigned short) + (4 + CTPB / 64) * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) + ZIG_N * sizeof(ZigEntry) + 2 * (size_t)H * sizeof(CoopRec); }
+static size_t coop_lds_bytes(int H, int NC = 1)
+{
+    return (size_t)H * (CTPB / NC) * 8 + (QCAP + QCAP1) * sizeof(unsigned short) + (4 + CTPB / 64) * sizeof(unsigned int) + (CTPB / 64) * sizeof(unsigned long long) +
+           ZIG_N * sizeof(ZigEntry) + 2 * (size_t)H * sizeof(CoopRec) + (NC > 1 ? 4 * (CTPB / NC) * sizeof(int) : 0);
+}
 
 // launch the Philox-driven step with the selected implementation
 template <bool WEIGH>
@@ -1026,12 +1077,24 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
 {
     // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 14 four workgroups share a CU, up to H = 21
     // three, and it is the faster one (rollouts: H = 14 3.4 vs 2.5e9 particle-steps/s, H = 21 1.97 vs 1.67e9); wider
-    // states leave it two workgroups or one and the per-thread kernel wins (H = 28: 1.08 vs 1.33e9, H = 56: 0.26 vs 0.79e9).
+    // states would leave it two workgroups or one (H = 28: 1.08 vs 1.33e9, H = 56: 0.26 vs 0.79e9).
     // The cooperative kernel takes the square root of the observation variance without the power-of-two scaling that
     // arguments below 2^-767 need; the argument is a positive integer times p (1 - p), so a parameter set with a test
     // probability in (0, 2^-700) always runs the per-thread kernel.
     if (!WEIGH && A.n == 1 && g_coop == 1) {                    // a lone particle: one lane per age bin
         k_step_one<<<dim3(1), dim3(64), 0, c->stream>>>(A, c->d_params);
+        return hipGetLastError();
+    }
+    // States of 18 to 28 ages run the cooperative kernel with every particle split over two threads, which brings the
+    // footprint per workgroup back to a narrow state's (ensembles of 4 10^6 trajectories: H = 18 2.14 vs 2.02, H = 21 1.88 vs
+    // 1.77, H = 28 1.44 vs 1.26e9 particle-steps/s).  Beyond that most bins are old ages whose draws are cheap and never
+    // rejected, the cooperative rounds have little to share, and the per-thread kernel is the faster one (four threads
+    // per particle, measured: H = 42 0.90 vs 0.92, H = 56 0.69 vs 0.76e9).
+    if (!c->tiny_p && g_coop == 1 && c->P.H >= 18 && c->P.H <= 28 && A.screen) {
+        const size_t ldw = coop_lds_bytes(c->P.H, 2);
+        const dim3 grid((unsigned)ceil_div(A.n, CTPB / 2));
+        if (c->P.D > 0) k_step_coop<WEIGH, true, 0, true, false, 2><<<grid, dim3(CTPB), ldw, c->stream>>>(A, c->d_params);
+        else k_step_coop<WEIGH, false, 0, true, false, 2><<<grid, dim3(CTPB), ldw, c->stream>>>(A, c->d_params);
         return hipGetLastError();
     }
     const size_t lds = coop_lds_bytes(c->P.H);

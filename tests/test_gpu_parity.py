@@ -784,7 +784,7 @@ def test_wide_state_retry_queue_overflow_bit_exact(testing_lib):
     _, mu, _ = orc.log_weights(st0, 0.3, 0)
     o = int(np.median(mu))
     try:
-        for impl in (2, 1):                  # forced cooperative kernel, then the default choice (per-thread at this width)
+        for impl in (2, 0):                  # one thread per particle: with the cooperative rounds, then without them (the default at this width)
             check(lib.epi_debug_step_impl(impl))
             st = st0
             b = _belief(pomdp, st)
@@ -796,6 +796,53 @@ def test_wide_state_retry_queue_overflow_bit_exact(testing_lib):
             _eq(b.download(), st)
     finally:
         check(lib.epi_debug_step_impl(1))
+
+
+@pytest.mark.parametrize("H,D,n", [(14, 1, 800), (18, 0, 257), (19, 3, 1100), (21, 0, 1500), (22, 0, 1500), (25, 1, 129), (27, 7, 640), (28, 0, 4001), (28, 2, 700), (29, 1, 1500), (43, 0, 900), (56, 0, 3000), (56, 3, 333), (64, 7, 450)])
+def test_wide_state_bit_exact(H, D, n):
+    """States of 18 to 28 infection ages have every particle stepped by two threads, each owning every other pair of
+    infection terms and the age bins that seed them; wider ones run one thread per particle.  Random parameter sets at
+    the edges of the sampler regimes, population sizes that leave the last workgroup partial: plain steps with
+    per-particle outputs, filter updates (the observation moments are summed in bin order by one of the two threads),
+    and rollouts with per-particle actions and the history rows, all against the oracle."""
+    rng = np.random.default_rng(500 + H + D)
+    N = int(rng.choice([5_000, 1_000_000, 300_000_000]))
+    p = rng.random(H)
+    p[rng.random(H) < 0.15] = 0.0
+    p[rng.random(H) < 0.1] = 1.0
+    p[rng.random(H) < 0.2] *= 1e-4
+    shapes = 10.0 ** rng.uniform(-5, 1, H)
+    shapes[rng.random(H) < 0.15] = 0.0
+    scales = 10.0 ** rng.uniform(-3, 0.3, H)
+    pomdp = em.make_pomdp(horizon=H, test_delay=D, N=N, pos_test_probs=list(p), Infdistributions=list(zip(shapes, scales)),
+                          symptomatic_isolation_prob=float(rng.random()), asymptomatic_prob=float(rng.random()))
+    orc = pyoracle.Oracle(pomdp.to_c())
+    st = random_states(pomdp, n, rng, scale=max(1, N // (4 * H + 10)))
+    a = float(rng.random())
+    b = _belief(pomdp, st)
+    exp = st
+    for step in range(2 if D else 1):                                 # (the second step finds the test pipeline filled)
+        o, r, fl = em.step_batch(b, a, a_prev=a if step else 0.0, seed=5, step=step)
+        exp, eo, er, _, efl = orc.step_batch(exp, a, a if step else 0.0, seed=5, step=step)
+        _eq(b.download(), exp)
+        assert (o == eo).all() and fl == efl and (r.view(np.uint64) == er.view(np.uint64)).all()
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    _, mu, _ = orc.log_weights(exp, a, 0)
+    obs = int(np.median(mu))
+    for step in range(2):
+        em.update(upd, b, em.Action(a), obs)
+        exp, info = orc.pf_update(exp, a, obs, SEED, step)
+        assert upd.last_flags == info["flags"]
+        want = info["lwmax"] + np.log(info["W"] / 2.0 ** pyoracle.lib().orc_frac_bits(n) / n) - 0.5 * np.log(2 * np.pi)
+        assert abs(upd.last_loglik - want) <= 1e-9 * max(1.0, abs(want))
+    _eq(b.download(), exp)
+    T = 4
+    acts = rng.random((n, T))
+    hist, rew, fl = em.rollout_batch(b, T, acts, seed=77, step0=3)
+    exp2, ehist, erew, efl = orc.rollout(exp, T, acts, a_prev0=a, seed=77, step0=3)      # (the belief remembers the last action taken on it)
+    _eq(b.download(), exp2)
+    assert (hist == ehist).all() and fl == efl and (rew.view(np.uint64) == erew.view(np.uint64)).all()
+    b.close()
 
 
 def test_sharded_filter_over_rccl_single_rank(tmp_path):

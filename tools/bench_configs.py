@@ -39,8 +39,8 @@ def scoring():
     print(f"scoring: {n_seq} sequences x {R} rollouts x {T} days in {dt:.3f} s = {n_seq * R * T / dt:.3e} particle-steps/s")
 
 
-def ensembles():
-    for H in (14, 28, 56):
+def ensembles(widths=(14, 28, 56)):
+    for H in widths:
         pomdp = em.make_pomdp(LOD=5, horizon=H)
         n, T = 10_000_000, 30
         acts = np.random.default_rng(H).random(n)
@@ -56,4 +56,7 @@ def ensembles():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["closed_loop", "scoring", "ensembles"]
     for name in which:
-        {"closed_loop": closed_loop, "scoring": scoring, "ensembles": ensembles}[name]()
+        if name.startswith("ensembles:"):               # ensembles:28 -- one state width
+            ensembles((int(name.split(":")[1]),))
+        else:
+            {"closed_loop": closed_loop, "scoring": scoring, "ensembles": ensembles}[name]()
