@@ -16,7 +16,7 @@
 //                 writes its index into the contiguous output slots it owns
 //                 (k_scatter_big: the long ranges of collapsed weights)
 //   k_export / k_import / k_gather / k_replicate   move resampled particles
-//   k_sums, k_suminf, k_qsel_hist   belief mean and order statistics
+//   k_sums, k_suminf, k_summary16, k_qsel_pass, k_qsel_narrow   belief mean and order statistics
 //   k_score_acc / k_score_mean      discounted reward of scenario rollouts
 //   k_ode_loss / k_sum_partials     ODE-model loss of an ensemble kept on the device
 //   k_init_*      initial particles;  k_lfact_fill  the log-factorial table
@@ -230,7 +230,7 @@ static const int LF_TABLE_N = 1 << 20; // tabulated log factorials (8 MB per con
 static const int SCAN_ITEMS = 8;       // fixed-point weights per thread in the scan kernels
 static const int SCAN_TILE = TPB * SCAN_ITEMS;
 
-static const size_t QSEL_HIST_BYTES = 4 * 2048 * sizeof(unsigned long long);   // histograms of the order-statistic selection (k_qsel_hist)
+static const size_t QSEL_HIST_BYTES = 4 * 2048 * sizeof(unsigned long long);   // histograms of the order-statistic selection (k_qsel_pass)
 static const size_t PIN_BYTES = 128 << 10;
 static const size_t SMALL_BYTES = 128 << 10;
 
@@ -1726,13 +1726,14 @@ __global__ __launch_bounds__(TPB) void k_init_simplex(int64_t n, int32_t* __rest
 // ---------------------------------------------------------------------------
 // order statistics of the infected total sum(I) over the particles of a belief
 //
-// Exact selection by narrowing windows, entirely on the device.  The kernel that computes the totals also finds their
-// minimum and maximum; the window [lo, lo + 2^W) starts as the smallest power-of-two span from the minimum that holds
-// every value.  Each pass histograms the values of the window into 2048 bins of 2^max(W - 11, 0), finds per quantile
-// the bin in which the wanted rank falls and makes that bin the next window; W = 0 ends it (at most three passes for
-// 31-bit values, two for the default population).  The first pass is common to all quantiles.  Every kernel's
-// workgroups add their LDS histograms to the global one; the workgroup that finishes last (a ticket) does the
-// narrowing and leaves histogram and ticket cleared, so the buffers are zero between calls.
+// Exact selection by narrowing windows, entirely on the device.  A window [lo, lo + 2^W) holds the wanted value of a
+// quantile; the first one, common to all quantiles, is [0, 2^bits(N)) for the default state shape (an infected total
+// is at most the population) and the smallest power-of-two span from the minimum that holds every value otherwise.
+// Each pass histograms the values of the window into 2048 bins of 2^max(W - 11, 0), finds per quantile the bin in
+// which the wanted rank falls and makes that bin the next window; W = 0 ends it (at most three passes for 31-bit
+// values, two for the default population).  For the default shape the first pass rides on the kernel that computes the
+// totals (and the column sums).  A pass's workgroups add their LDS histograms to the global one; a single workgroup
+// launched after them narrows the windows and clears the histogram, so the buffers are zero between calls.
 // ---------------------------------------------------------------------------
 constexpr int QSEL_MAX = 4;            // quantiles per call
 constexpr int QSEL_BINS = 2048;
@@ -1785,14 +1786,62 @@ struct DigitRun {
     __device__ __forceinline__ void flush(unsigned int* s_h) { if (count) atomicAdd(&s_h[digit], count); count = 0u; }
 };
 
-// One pass.  Launched QSEL_MAX_PASSES times; a pass that finds the selection finished returns at once.
-__global__ __launch_bounds__(QTPB) void k_qsel_pass(int64_t n, const int32_t* __restrict__ v, QselState* __restrict__ st,
+// One workgroup of THREADS threads: every quantile's window becomes the bin of the pass's histogram that holds its rank
+// (the state's lo, rank, W are the pass's); clears the histogram.  s_part: THREADS / 64 words of LDS.
+template <int THREADS>
+__device__ __forceinline__ void qsel_narrow(QselState* __restrict__ st, unsigned long long* __restrict__ hist, unsigned long long* s_part)
+{
+    constexpr int per = QSEL_BINS / THREADS;                            // bins per thread
+    const int W = st->W, nq = st->nq, shared = st->shared, nh = shared ? 1 : nq;
+    const int shift = W > QSEL_LOG_BINS ? W - QSEL_LOG_BINS : 0;
+    int32_t lo[QSEL_MAX];
+    long long rank[QSEL_MAX];
+    for (int j = 0; j < QSEL_MAX; j++) { lo[j] = st->lo[j]; rank[j] = st->rank[j]; }
+    __syncthreads();                                                    // every thread has the pass's state before one of them replaces it
+    for (int j = 0; j < nq; j++) {
+        const unsigned long long* h = hist + (shared ? 0 : (size_t)j * QSEL_BINS);
+        const long long want = rank[j];
+        unsigned long long c[per], tot = 0ULL;
+        for (int k = 0; k < per; k++) { c[k] = h[threadIdx.x * per + k]; tot += c[k]; }
+        // inclusive prefix sum of the threads' totals: waves by shuffles, then the wave totals through LDS
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned long long incl = tot;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = shfl_up_u64(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        unsigned long long before = incl - tot;
+        for (int w = 0; w < wv; w++) before += s_part[w];
+        __syncthreads();
+        if ((long long)before < want && want <= (long long)(before + tot)) {          // exactly one thread
+            unsigned long long acc = before;
+            int k = 0;
+            for (; k < per - 1; k++) { if ((long long)(acc + c[k]) >= want) break; acc += c[k]; }
+            st->lo[j] = lo[shared ? 0 : j] + (int32_t)((unsigned int)(threadIdx.x * per + k) << shift);
+            st->rank[j] = want - (long long)acc;
+        }
+        // fewer values inside the window than the rank asks for (a total outside [0, 2^bits(N)): a state that breaks the
+        // population invariant): the selection is marked unfinished, which the host reports
+        if (threadIdx.x == THREADS - 1 && want > (long long)(before + tot)) st->rank[j] = -1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nh * QSEL_BINS; i += THREADS) hist[i] = 0ULL;
+    if (threadIdx.x == 0) {
+        bool short_of = false;
+        for (int j = 0; j < nq; j++) short_of |= st->rank[j] < 0;
+        st->W = short_of ? 31 : shift; st->shared = 0;
+    }
+}
+
+// One pass: the histograms of the values inside the windows.  A pass that finds the selection finished returns at once.
+__global__ __launch_bounds__(QTPB) void k_qsel_pass(int64_t n, const int32_t* __restrict__ v, const QselState* __restrict__ st,
                                                      unsigned long long* __restrict__ hist)
 {
     __shared__ unsigned int s_h[QSEL_MAX * QSEL_BINS];
-    __shared__ unsigned long long s_part[QTPB];
     const int W = st->W;
-    if (W == 0) return;                                                 // uniform over the grid: no ticket is taken
+    if (W == 0) return;
     const int nq = st->nq, shared = st->shared, nh = shared ? 1 : nq;
     const int shift = W > QSEL_LOG_BINS ? W - QSEL_LOG_BINS : 0;
     int32_t lo[QSEL_MAX];
@@ -1823,40 +1872,15 @@ __global__ __launch_bounds__(QTPB) void k_qsel_pass(int64_t n, const int32_t* __
     __syncthreads();
     for (int i = threadIdx.x; i < nh * QSEL_BINS; i += QTPB)
         if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
-    if (!last_workgroup(&st->done)) return;
-    // the last workgroup narrows every quantile's window to the bin that holds its rank
-    constexpr int per = QSEL_BINS / QTPB;                               // bins per thread
-    for (int j = 0; j < nq; j++) {
-        const unsigned long long* h = hist + (shared ? 0 : (size_t)j * QSEL_BINS);
-        const long long want = st->rank[j];
-        unsigned long long c[per], tot = 0ULL;
-        for (int k = 0; k < per; k++) {
-            c[k] = __hip_atomic_load(&h[threadIdx.x * per + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tot += c[k];
-        }
-        // inclusive prefix sum of the threads' totals: waves by shuffles, then the wave totals through LDS
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        unsigned long long incl = tot;
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long o = shfl_up_u64(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) s_part[wv] = incl;
-        __syncthreads();
-        unsigned long long before = incl - tot;
-        for (int w = 0; w < wv; w++) before += s_part[w];
-        __syncthreads();
-        if ((long long)before < want && want <= (long long)(before + tot)) {          // exactly one thread
-            unsigned long long acc = before;
-            int k = 0;
-            for (; k < per - 1; k++) { if ((long long)(acc + c[k]) >= want) break; acc += c[k]; }
-            st->lo[j] = lo[shared ? 0 : j] + (int32_t)((unsigned int)(threadIdx.x * per + k) << shift);
-            st->rank[j] = want - (long long)acc;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nh * QSEL_BINS; i += QTPB) hist[i] = 0ULL;
-    if (threadIdx.x == 0) { st->done = 0u; st->W = shift; st->shared = 0; }
+}
+
+// after a pass (a kernel of its own rather than a ticket among the pass's workgroups: same-address atomics queue up at
+// about 70 ns each, which kept the passes to a few dozen workgroups)
+__global__ __launch_bounds__(QTPB) void k_qsel_narrow(QselState* __restrict__ st, unsigned long long* __restrict__ hist)
+{
+    __shared__ unsigned long long s_part[QTPB / 64];
+    if (st->W == 0) return;
+    qsel_narrow<QTPB>(st, hist, s_part);
 }
 
 // Infected total of every particle (through the ancestor index), their minimum and maximum, and the start of a
@@ -1896,19 +1920,27 @@ __global__ __launch_bounds__(TPB) void k_suminf(int64_t n, const int32_t* __rest
 }
 
 // The same for the default state shape (H = 14, no pending tests: 16 rows) together with the column sums of the
-// belief mean: every row is read once, through the ancestor index, for all results.  part: per workgroup 16 column
-// sums, then minimum and maximum of the totals (18 long long); k_summary_finish adds them up.
+// belief mean and the first pass of the selection: every row is read once, through the ancestor index, for all
+// results.  part: per workgroup 16 column sums (k_summary_finish adds them up).  W0 > 0: the totals are also counted
+// into the histogram of the window [0, 2^W0) (2^W0 above the population, so every total falls inside).
 constexpr int SUMMARY_ROWS = 16;
-constexpr int SUMMARY_SLOT = SUMMARY_ROWS + 2;
+constexpr int SUMMARY_SLOT = SUMMARY_ROWS;
 constexpr int SUMMARY_MAX_GROUPS = 512;
 __global__ __launch_bounds__(TPB) void k_summary16(int64_t n, const int32_t* __restrict__ src, int64_t stride, const int32_t* __restrict__ anc,
-                                                    int32_t* __restrict__ out, long long* __restrict__ part, int want_quant)
+                                                    int32_t* __restrict__ out, long long* __restrict__ part, int W0, unsigned long long* __restrict__ hist)
 {
     __shared__ long long s_sum[TPB / 64][SUMMARY_SLOT];
+    __shared__ unsigned int s_h[QSEL_BINS];
     long long acc[SUMMARY_ROWS];
 #pragma unroll
     for (int r = 0; r < SUMMARY_ROWS; r++) acc[r] = 0;
-    int32_t vmin = 0x7fffffff, vmax = 0;
+    const int want_quant = W0 > 0;
+    const int shift0 = W0 > QSEL_LOG_BINS ? W0 - QSEL_LOG_BINS : 0;
+    if (want_quant) {
+        for (int i = threadIdx.x; i < QSEL_BINS; i += TPB) s_h[i] = 0u;
+        __syncthreads();
+    }
+    DigitRun run;
     // two particles per trip: their 34 loads are in flight together
     const int64_t sweep = (int64_t)gridDim.x * TPB * 2;
     for (int64_t base = (int64_t)blockIdx.x * TPB * 2 + threadIdx.x; base < n; base += sweep) {
@@ -1927,54 +1959,48 @@ __global__ __launch_bounds__(TPB) void k_summary16(int64_t n, const int32_t* __r
         }
         if (want_quant) {
             out[m0] = t0;
-            if (have1) out[m1] = t1;
+            if (t0 >= 0 && ((unsigned int)t0 >> W0) == 0u) run.add((unsigned int)t0 >> shift0, s_h);
+            if (have1) {
+                out[m1] = t1;
+                if (t1 >= 0 && ((unsigned int)t1 >> W0) == 0u) run.add((unsigned int)t1 >> shift0, s_h);
+            }
         }
-        vmin = t0 < vmin ? t0 : vmin; vmax = t0 > vmax ? t0 : vmax;
-        vmin = t1 < vmin ? t1 : vmin; vmax = t1 > vmax ? t1 : vmax;             // without m1, t1 repeats t0's particle
+    }
+    if (want_quant) {
+        run.flush(s_h);
+        __syncthreads();
+        for (int i = threadIdx.x; i < QSEL_BINS; i += TPB)
+            if (s_h[i]) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
     }
     // wave, then workgroup, then this workgroup's slot
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int32_t a = __shfl_down(vmin, d, 64), b = __shfl_down(vmax, d, 64);
-        vmin = a < vmin ? a : vmin; vmax = b > vmax ? b : vmax;
-    }
 #pragma unroll
     for (int r = 0; r < SUMMARY_ROWS; r++) {
         unsigned long long v = (unsigned long long)acc[r];
         for (int d = 32; d >= 1; d >>= 1) v += shfl_down_u64(v, d);
         if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6][r] = (long long)v;
     }
-    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6][SUMMARY_ROWS] = vmin; s_sum[threadIdx.x >> 6][SUMMARY_ROWS + 1] = vmax; }
     __syncthreads();
     if (threadIdx.x < SUMMARY_SLOT) {
         long long t = s_sum[0][threadIdx.x];
-        for (int w = 1; w < TPB / 64; w++) {
-            const long long o = s_sum[w][threadIdx.x];
-            if (threadIdx.x < SUMMARY_ROWS) t += o;
-            else if (threadIdx.x == SUMMARY_ROWS) t = o < t ? o : t;
-            else t = o > t ? o : t;
-        }
+        for (int w = 1; w < TPB / 64; w++) t += s_sum[w][threadIdx.x];
         part[(int64_t)blockIdx.x * SUMMARY_SLOT + threadIdx.x] = t;
     }
 }
 
 // One workgroup: adds up the slots k_summary16's workgroups left (thread t takes slots t, t + 256, ..., then the 256
-// partial results are combined in thread order), adds the column sums to `sums` and starts the selection.  A kernel of
-// its own rather than a ticket in k_summary16: with hundreds of workgroups the ticket atomics alone took 30 us.
+// partial results are combined in thread order) and adds the column sums to `sums`; W0 > 0: starts the selection with the
+// window [0, 2^W0) and narrows it by the histogram k_summary16 has filled.  A kernel of its own rather than a ticket in
+// k_summary16: with hundreds of workgroups the ticket atomics alone took 30 us.
 __global__ __launch_bounds__(TPB) void k_summary_finish(int groups, const long long* __restrict__ part, long long* __restrict__ sums,
-                                                         QselRanks R, QselState* __restrict__ st, int want_quant)
+                                                         QselRanks R, QselState* __restrict__ st, int W0, unsigned long long* __restrict__ hist)
 {
     __shared__ long long s_all[TPB][SUMMARY_SLOT];
+    __shared__ unsigned long long s_part[TPB / 64];
     long long t[SUMMARY_SLOT];
     for (int r = 0; r < SUMMARY_ROWS; r++) t[r] = 0;
-    t[SUMMARY_ROWS] = 0x7fffffff; t[SUMMARY_ROWS + 1] = 0;
     for (int g = threadIdx.x; g < groups; g += TPB) {
 #pragma unroll
-        for (int r = 0; r < SUMMARY_SLOT; r++) {
-            const long long o = part[(int64_t)g * SUMMARY_SLOT + r];
-            if (r < SUMMARY_ROWS) t[r] += o;
-            else if (r == SUMMARY_ROWS) t[r] = o < t[r] ? o : t[r];
-            else t[r] = o > t[r] ? o : t[r];
-        }
+        for (int r = 0; r < SUMMARY_SLOT; r++) t[r] += part[(int64_t)g * SUMMARY_SLOT + r];
     }
     for (int r = 0; r < SUMMARY_SLOT; r++) s_all[threadIdx.x][r] = t[r];
     __syncthreads();
@@ -1986,12 +2012,7 @@ __global__ __launch_bounds__(TPB) void k_summary_finish(int groups, const long l
     if (stage1) {
         const int r = threadIdx.x % SUMMARY_SLOT, chunk = threadIdx.x / SUMMARY_SLOT;
         u = s_all[chunk * CHUNK][r];
-        for (int k = 1; k < CHUNK; k++) {
-            const long long o = s_all[chunk * CHUNK + k][r];
-            if (r < SUMMARY_ROWS) u += o;
-            else if (r == SUMMARY_ROWS) u = o < u ? o : u;
-            else u = o > u ? o : u;
-        }
+        for (int k = 1; k < CHUNK; k++) u += s_all[chunk * CHUNK + k][r];
     }
     __syncthreads();
     if (stage1) s_all[threadIdx.x / SUMMARY_SLOT][threadIdx.x % SUMMARY_SLOT] = u;
@@ -1999,17 +2020,17 @@ __global__ __launch_bounds__(TPB) void k_summary_finish(int groups, const long l
     if (threadIdx.x < SUMMARY_SLOT) {
         const int r = threadIdx.x;
         u = s_all[0][r];
-        for (int k = 1; k < CHUNKS; k++) {
-            const long long o = s_all[k][r];
-            if (r < SUMMARY_ROWS) u += o;
-            else if (r == SUMMARY_ROWS) u = o < u ? o : u;
-            else u = o > u ? o : u;
-        }
-        s_all[0][r] = u;
-        if (r < SUMMARY_ROWS) sums[r] += u;
+        for (int k = 1; k < CHUNKS; k++) u += s_all[k][r];
+        sums[r] += u;
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && want_quant) qsel_begin(st, R, (int32_t)s_all[0][SUMMARY_ROWS], (int32_t)s_all[0][SUMMARY_ROWS + 1]);
+    if (W0 > 0) {
+        if (threadIdx.x == 0) {
+            for (int j = 0; j < QSEL_MAX; j++) { st->lo[j] = 0; st->rank[j] = j < R.nq ? R.rank[j] : 1; }
+            st->nq = R.nq; st->W = W0; st->shared = 1;
+        }
+        __syncthreads();
+        qsel_narrow<TPB>(st, hist, s_part);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -3667,19 +3688,29 @@ static QselRanks qsel_ranks(int64_t n, const double* q, int nq)
     return R;
 }
 
-// the passes of a selection over the n totals in dv (its start is already in the state)
-static int enqueue_qsel_passes(epi_ctx* c, int64_t n, const int32_t* dv)
+// bits of the population: an infected total is at most N, so [0, 2^bits) holds every total
+static int population_bits(const epi_ctx* c)
+{
+    int bits = 1;
+    while (bits < 31 && (c->P.N >> bits) != 0) bits++;
+    return bits;
+}
+
+// the passes of a selection over the n totals in dv (its start is already in the state); first_done: the first pass has
+// been made (by k_summary16 / k_summary_finish)
+static int enqueue_qsel_passes(epi_ctx* c, int64_t n, const int32_t* dv, bool first_done)
 {
     unsigned long long* const dh = reinterpret_cast<unsigned long long*>(c->d_qsel);
     QselState* const st = reinterpret_cast<QselState*>(c->d_qsel + QSEL_HIST_BYTES);
-    int64_t g = ceil_div(n, (int64_t)QTPB * 16);                       // two trips of eight values per thread; few workgroups (ticket)
+    int64_t g = ceil_div(n, (int64_t)QTPB * 8);                        // one trip of eight values per thread
     g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
-    // an infected total is at most the population N: the first window spans at most bits(N) bits, each pass resolves 11
-    int bits = 0;
-    while (bits < 31 && (c->P.N >> bits) != 0) bits++;
+    // the first window spans at most bits(N) bits, each pass resolves 11
+    const int bits = population_bits(c);
     const int passes = bits <= QSEL_LOG_BINS ? 1 : (bits <= 2 * QSEL_LOG_BINS ? 2 : QSEL_MAX_PASSES);
-    for (int pass = 0; pass < passes; pass++)
+    for (int pass = first_done ? 1 : 0; pass < passes; pass++) {
         k_qsel_pass<<<dim3((unsigned)g), dim3(QTPB), 0, c->stream>>>(n, dv, st, dh);
+        k_qsel_narrow<<<1, QTPB, 0, c->stream>>>(st, dh);
+    }
     HIPCHECK(hipGetLastError());
     return EPI_OK;
 }
@@ -3695,12 +3726,16 @@ static int enqueue_summary(epi_ctx* c, epi_belief* b, bool want_sums, const doub
     const QselRanks R = qsel_ranks(n, q, nq);
     const int32_t* anc = b->has_anc ? b->anc : nullptr;
     static_assert(sizeof(long long) * SUMMARY_SLOT * SUMMARY_MAX_GROUPS <= SMALL_BYTES, "partial results outgrew the context's small buffer");
+    bool first_done = false;
     if (want_sums && b->rows == SUMMARY_ROWS) {
         int64_t gs = ceil_div(n, (int64_t)TPB * 8);
         gs = gs < 1 ? 1 : (gs > SUMMARY_MAX_GROUPS ? SUMMARY_MAX_GROUPS : gs);
         long long* const part = reinterpret_cast<long long*>(c->d_small);
-        k_summary16<<<dim3((unsigned)gs), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, anc, dv, part, nq > 0);
-        k_summary_finish<<<1, TPB, 0, c->stream>>>((int)gs, part, c->d_sums, R, st, nq > 0);
+        unsigned long long* const dh = reinterpret_cast<unsigned long long*>(c->d_qsel);
+        const int W0 = nq > 0 ? population_bits(c) : 0;
+        k_summary16<<<dim3((unsigned)gs), dim3(TPB), 0, c->stream>>>(n, b->buf[b->cur], b->stride, anc, dv, part, W0, dh);
+        k_summary_finish<<<1, TPB, 0, c->stream>>>((int)gs, part, c->d_sums, R, st, W0, dh);
+        first_done = true;
     } else {
         if (want_sums) { int rc = enqueue_sums(c, b); if (rc) return rc; }
         if (nq) {
@@ -3711,7 +3746,7 @@ static int enqueue_summary(epi_ctx* c, epi_belief* b, bool want_sums, const doub
         }
     }
     HIPCHECK(hipGetLastError());
-    if (nq) return enqueue_qsel_passes(c, n, dv);
+    if (nq) return enqueue_qsel_passes(c, n, dv, first_done);
     return EPI_OK;
 }
 

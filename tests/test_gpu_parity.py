@@ -332,6 +332,31 @@ def test_closed_loop_days_bit_exact(delay):
     assert upd.step == len(acts)
 
 
+@pytest.mark.parametrize("N,mu", [(1500, 40.0), (2047, 60.0), (2048, 60.0), (300_000_000, 9_000_000.0)])
+def test_closed_loop_order_statistics_for_small_and_large_populations(N, mu):
+    """The first pass of the selection rides on the kernel of the column sums with the window [0, 2^bits(N)): a
+    population below 2^11 is settled by that pass alone, one of 3 10^8 needs two more."""
+    pomdp = em.make_pomdp(LOD=5, N=N)
+    orc = pyoracle.Oracle(pomdp.to_c())
+    n = 6001
+    st = orc.init_normal(n, mu, mu / 2, 41)
+    tr = orc.init_normal(1, mu, mu / 2, 42)
+    b, true = _belief(pomdp, st), _belief(pomdp, tr)
+    upd = em.BootstrapFilter(pomdp, n, seed=SEED)
+    qs = np.array([0.0, 0.25, 0.5, 1.0])
+    res = em.interface.closed_loop_days(true, b, upd, [0.3, 0.2], 555, 0, q=qs, want_sums=True)
+    a_prev = 0.0
+    for j, a in enumerate([0.3, 0.2]):
+        tr, o, r, _, fl = orc.step_batch(tr, a, a_prev=a_prev, seed=555, step=j)
+        st, info = orc.pf_update(st, a, int(o[0]), SEED, j)
+        tot = np.sort(st[1].sum(axis=1))
+        ranks = np.clip(np.ceil(qs * n).astype(np.int64), 1, n)
+        assert (res["quant"][j] == tot[ranks - 1]).all(), (j, res["quant"][j], tot[ranks - 1])
+        assert res["sums"][j][0] == st[0].sum() and (res["sums"][j][2:2 + pomdp.horizon] == st[1].sum(axis=0)).all()
+        a_prev = a
+    _eq(b.download(), st)
+
+
 def test_closed_loop_days_rejects_bad_arguments():
     pomdp = em.make_pomdp(LOD=5)
     ctx = em.interface.context_for(pomdp)
