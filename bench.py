@@ -29,10 +29,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak
 SIMD_CLOCK_HZ = 2.4e9           # nominal engine clock
 N_SIMD = 256 * 4                # 256 CUs x 4 SIMDs
 # issue cycles of one wave64 vector instruction on its SIMD with the SIMD's other waves issuing too, by counter class
-# (tools/ubench.hip: binary64 add / mul / fma 5.2-5.6, conversions 3-4, binary32 fma 4.7, 64-bit integer multiply-add
-# 7.2, 32-bit integer 2.5-2.8, binary32 transcendentals ~7, binary64 reciprocal ~16, compares / selects / moves ~3)
-VALU_ISSUE_CYCLES = {"valu_add_f64": 5.2, "valu_mul_f64": 5.6, "valu_fma_f64": 5.3, "valu_trans_f64": 16.0, "valu_cvt": 3.5,
-                     "valu_fma_f32": 4.7, "valu_int64": 7.2, "valu_int32": 2.7, "valu_trans_f32": 7.0, "other": 3.0}
+# (tools/ubench.hip: binary64 add / mul / fma 5.2-5.6, conversions 3-4, binary32 fma 4.7 (add and multiply 2.4), 64-bit
+# integer multiply-add 7.0, 32-bit integer 2.5-2.8 (high half of a product 5.2), binary32 transcendentals ~9, binary64
+# reciprocal ~16, compares / selects / moves 2.5-3.2)
+VALU_ISSUE_CYCLES = {"valu_add_f64": 5.2, "valu_mul_f64": 5.6, "valu_fma_f64": 5.3, "valu_trans_f64": 16.0, "valu_cvt": 3.2,
+                     "valu_fma_f32": 4.7, "valu_int64": 7.0, "valu_int32": 3.2, "valu_trans_f32": 9.0, "other": 2.9}
 SEED = 0x5EED
 ACTION = 0.2
 import datetime
@@ -46,6 +47,18 @@ def alg_bytes_per_particle_step(H: int, D: int) -> int:
     fp64 weights: read prior once + write posterior once + write weight + read weight."""
     W = 2 + H + D * (H - 1)
     return 2 * 4 * W + 16
+
+
+def step_kernel_name(H: int, D: int) -> str:
+    """The instantiation the library launches for the weighing step of an update (launch_step in epi_gfx950.hip)."""
+    delay = "true" if D > 0 else "false"
+    if H == 14 and D == 0:
+        return "k_step_coop<true, false, 14, true, true, 1>"
+    if H < 18:
+        return f"k_step_coop<true, {delay}, 0, true, false, 1>"
+    if H <= 28:
+        return f"k_step_coop<true, {delay}, 0, true, false, 2>"
+    return f"k_step<true, 0, {delay}, true>"
 
 
 def observations(pomdp, count):
@@ -397,11 +410,15 @@ def main():
     value = n * args.steps / dt
     n_launch = n // world                           # particles one launch of the fused kernel processes
     achieved = balg * n_launch / (kms * 1e-3) / 1e9 if kms > 0 else None
-    traffic = None
+    # traffic and the instruction mix below are NOT measured in this run: they come from counter passes of the same
+    # kernel committed under profiles/ (rocprofv3 --pmc cannot run inside the timed benchmark); `source` says which
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and H == 14 and D == 0:
         try:
-            traffic = json.load(open(tpath))["k_step_hbm_bytes_per_particle"] * n_launch
+            tj = json.load(open(tpath))
+            traffic = tj["k_step_hbm_bytes_per_particle"] * n_launch
+            traffic_source = f"profiles/pmc_traffic.json (committed counter pass, build {tj.get('build', 'unrecorded')}): bytes per particle x particles per launch"
         except Exception:
             traffic = None
     # The step kernel is bound by vector-instruction issue, not by HBM.  Next to the HBM roofline: the SIMD cycles one
@@ -412,26 +429,30 @@ def main():
     vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
     if kms > 0 and os.path.exists(vpath) and H == 14 and D == 0:
         try:
-            mix = json.load(open(vpath))["insts_per_wave_step"]
+            vj = json.load(open(vpath))
+            mix = vj["insts_per_wave_step"]
             cyc = kms * 1e-3 * SIMD_CLOCK_HZ * N_SIMD / (n_launch / 64.0)
             classed = sum(mix[k] for k in VALU_ISSUE_CYCLES if k != "other")
             need = sum(mix[k] * c for k, c in VALU_ISSUE_CYCLES.items() if k != "other")
             need += (mix["valu"] - classed) * VALU_ISSUE_CYCLES["other"]
             issue = {"bound": "valu-issue", "valu_insts_per_wave_step": mix["valu"], "simd_cycles_per_wave_step": cyc,
-                     "issue_cycles_of_the_mix": need, "frac": need / cyc}
+                     "issue_cycles_of_the_mix": need, "frac": need / cyc,
+                     "source": f"kernel time: this run; instruction mix: profiles/pmc_valu.json (committed counter pass, build {vj.get('build', 'unrecorded')}); "
+                               "issue cost per class: tools/ubench.hip"}
         except Exception:
             issue = None
     out = {
         "metric": "particle-steps/sec (whole node) at 10^8 particles; % of HBM roofline",
         "value": value, "unit": "particle-steps/s", "n_gpus": args.gpus, "world_size": world, "backend": backend, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "dtype_note": "int32 compartment counts in HBM; sampler and weight arithmetic in binary64", "data": "synthetic",
+        "dtype": "f64", "dtype_note": "int32 compartment counts in HBM; observation weights, resampling and the samplers' defining acceptance tests in binary64, "
+                                       "sampler proposals (inversion recurrence, rejection hats, normal strips) in binary32", "data": "synthetic",
         "config": {"workload": "bootstrap particle-filter update (predict+weight+systematic resample)",
                    "particles": n, "H": H, "test_delay": D, "N": pomdp.N, "action": ACTION, "seed": SEED,
                    "sharding": f"by index over {args.gpus} rank(s)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                     "kernel": ("k_step_coop<true, false, 14, true, true>" if (D == 0 and H == 14) else "k_step_coop<true, %s, 0, true, false>" % ("true" if D > 0 else "false")), "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": step_kernel_name(H, D), "kernel_ms": kms, "alg_bytes_per_particle_step": balg},
         "issue": issue,
         "diagnostics": diag,
     }

@@ -1,9 +1,9 @@
 #!/bin/bash
 # The round's final measurement set on one box (GPU box, repository root): kernel statistics of the bench command, the
-# default bench line, the SQ and TCC counter passes.  Results under gpurun_out/r2_final; copy what is kept to profiles/.
+# default bench line, the SQ and TCC counter passes.  Results under gpurun_out/<round>_final (ROUND=r3 by default); copy what is kept to profiles/.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2_final
+O=gpurun_out/${ROUND:-r3}_final
 rm -rf $O gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c gpurun_out/pmc_fetch gpurun_out/pmc_write /tmp/prof_final
 mkdir -p $O/pmc
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $O/prof.log 2>&1

@@ -59,4 +59,6 @@ if None not in (ff, wf, step_f, step_w):
     if out:
         json.dump({"k_step_hbm_bytes_per_particle": tot, "k_step_fetch_bytes_per_particle": step_f * ff,
                    "k_step_write_bytes_per_particle": step_w * wf, "fetch_factor": ff, "write_factor": wf,
-                   "particles": n, "raw": rep}, open(out, "w"), indent=1)
+                   "particles": n, "build": __import__("os").environ.get("EPI_BUILD", "unrecorded"),
+                   "raw": {k: {kk: vv[-4:] for kk, vv in v.items()} for k, v in rep.items() if "k_step" in k or "k_gather" in k or "k_w" in k}},
+                  open(out, "w"), indent=1)
