@@ -603,6 +603,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 {
     static_assert(NC == 1 || (HC == 0 && !FULL), "chunked particles: run-time H, bounds-checked");
     static_assert(NC == 1 || NC == 2 || NC == 4, "one share per whole number of waves");
+    // The weighing step of an update has no per-particle outputs (observation, reward, new infections, history row: those
+    // belong to plain steps and rollouts), so its build does not carry their sums through the sampler phases.
+    constexpr bool OUTS = !WEIGH;
     constexpr int PW = CTPB / NC;                                                  // particles per workgroup
     const epi_params& P = Dp->P;
     // Arguments needed only at the end of the kernel are re-read from the kernel-argument segment there (scalar
@@ -657,6 +660,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[lp], v); };
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
+    if (WEIGH && tid < CTPB / 64) s_max[tid] = 0ULL;
     if constexpr (NC > 1) for (int r = tid; r < 4 * PW; r += CTPB) acc[r] = 0;
     for (int r = tid; r < ZIG_N; r += CTPB) ztab[r] = Dp->zig.e[r];
     for (int r = tid; r < 2 * H; r += CTPB) {
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
 
     // ---- A: stage the bins, observation moments -----------------------------------
     if (active) {
-        if (lead) { S = ld_in(0); R = ld_in(1); R_pre = R; }
+        // (S and R are read at the end, where they are needed: R counts the step's recoveries from zero until then)
         double tm = 0.0, tv = 0.0;
         // the observation moments are sums in bin order: with chunks, the lead thread visits every bin for them
         // (re-reading the other chunks' rows, which the cache holds) and stages only its own
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (nt < 0) flags |= EPI_F_NEG_NT;
             if (owns(i)) {
                 slots[i * PW + lp] = make_int2(Ii, nt);
-                suminf_pre += Ii;
+                if constexpr (OUTS) suminf_pre += Ii;
             }
             if (WEIGH && moments) {
                 const double pi = P.p[i];
@@ -716,6 +720,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             code = order_code(lw);
         }
     }
+    // the largest log weight of the wave is collected in LDS here (the barriers of the later phases order it before
+    // thread 0 reads it at the end), so that the code does not occupy a register pair through the sampler phases; by LDS
+    // atomics rather than shuffles, whose lane addresses the compiler would keep for the reduction of the flags at the end
+    if constexpr (WEIGH) { if (code) atomicMax(&s_max[tid >> 6], code); }
 
     EPI_STAMP(0);
     // ---- B: the table-free part of attempt 0 of both binomials of every bin --------------------------------
@@ -924,9 +932,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 else if (i + 1 < H) st_out(tests_row(H, r - 1, i + 1), ts);
             }
             if (Ii < 0) flags |= EPI_F_NEG_I;                                      // simulate.jl:117
-            o_sum += pos;
+            if constexpr (OUTS) o_sum += pos;
             if (it == 0) R += Ii;                                                  // simulate.jl:144
-            else { st_out(2 + it, Ii); sum_inf += Ii; }                            // simulate.jl:145
+            else { st_out(2 + it, Ii); if constexpr (OUTS) sum_inf += Ii; }        // simulate.jl:145
             const double shape = k_it * (double)Ii;                                // init.jl:71-78
             uint32_t wz = z_odd, wu = w_odd;
             if ((it & 1) == 0) {                                                   // an even term generates the block of its pair
@@ -970,9 +978,11 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     if constexpr (NC > 1) {
         if (active && !lead) {
             if (R) atomicAdd(&acc[lp], R);
-            if (o_sum) atomicAdd(&acc[PW + lp], o_sum);
-            if (sum_inf) atomicAdd(&acc[2 * PW + lp], sum_inf);
-            if (suminf_pre) atomicAdd(&acc[3 * PW + lp], suminf_pre);
+            if constexpr (OUTS) {
+                if (o_sum) atomicAdd(&acc[PW + lp], o_sum);
+                if (sum_inf) atomicAdd(&acc[2 * PW + lp], sum_inf);
+                if (suminf_pre) atomicAdd(&acc[3 * PW + lp], suminf_pre);
+            }
         }
     }
 
@@ -1020,7 +1030,17 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     EPI_STAMP(4);
     // ---- F: infection sum in bin order, new infections, outputs --------------------------------
     if (active && lead) {
-        if constexpr (NC > 1) { R += acc[lp]; o_sum += acc[PW + lp]; sum_inf += acc[2 * PW + lp]; suminf_pre += acc[3 * PW + lp]; }
+        // the addresses of this phase's loads and stores are formed here, not ahead of the sampler phases (where the
+        // compiler would otherwise compute them, to carry them through every phase in registers it does not have)
+        int lpf = lp;
+        asm volatile("" : "+v"(lpf));
+        auto st_end = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[lpf], v); };
+        S = ld_in(0); R_pre = ld_in(1);
+        R += R_pre;
+        if constexpr (NC > 1) {
+            R += acc[lp];
+            if constexpr (OUTS) { o_sum += acc[PW + lp]; sum_inf += acc[2 * PW + lp]; suminf_pre += acc[3 * PW + lp]; }
+        }
         double infsum = 0.0;
 #pragma unroll 1
         for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * PW + lp];   // simulate.jl:38-41
@@ -1028,34 +1048,31 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
         else newi = (int32_t)__builtin_floor(div_unscaled((double)S, (double)denom) * infsum);  // simulate.jl:42-44
-        st_out(2, newi);                                                                        // simulate.jl:147
-        st_out(0, S - newi);                                                                    // simulate.jl:148
-        st_out(1, R);
+        st_end(2, newi);                                                                        // simulate.jl:147
+        st_end(0, S - newi);                                                                    // simulate.jl:148
+        st_end(1, R);
         const bool real = !FULL || m < Ak->n;                                                   // not a surplus thread of a padded launch
         if (!real) flags = 0u;
-        if (Ak->o_out && real) Ak->o_out[m] = o_sum;
-        if (Ak->newinf_out && real) Ak->newinf_out[m] = newi;
-        if (Ak->r_out && real) {
-            const int64_t prow = Ak->a_div > 1 ? m / Ak->a_div : m;
-            const double ap = Ak->a_prev_dev ? Ak->a_prev_dev[prow * Ak->a_row_stride + Ak->a_prev_col] : Ak->a_prev;
-            Ak->r_out[m] = reward_of(P, sum_inf + newi, a, ap);
-        }
-        if (Ak->hist && real) {
-            int32_t* hist = Ak->hist;
-            const int64_t hn = Ak->n;
-            hist[m] = S; hist[hn + m] = suminf_pre; hist[2 * hn + m] = R_pre; hist[3 * hn + m] = o_sum;
+        if constexpr (OUTS) {
+            if (Ak->o_out && real) Ak->o_out[m] = o_sum;
+            if (Ak->newinf_out && real) Ak->newinf_out[m] = newi;
+            if (Ak->r_out && real) {
+                const int64_t prow = Ak->a_div > 1 ? m / Ak->a_div : m;
+                const double ap = Ak->a_prev_dev ? Ak->a_prev_dev[prow * Ak->a_row_stride + Ak->a_prev_col] : Ak->a_prev;
+                Ak->r_out[m] = reward_of(P, sum_inf + newi, a, ap);
+            }
+            if (Ak->hist && real) {
+                int32_t* hist = Ak->hist;
+                const int64_t hn = Ak->n;
+                hist[m] = S; hist[hn + m] = suminf_pre; hist[2 * hn + m] = R_pre; hist[3 * hn + m] = o_sum;
+            }
         }
     }
     unsigned int wf = flags;
     for (int d = 32; d >= 1; d >>= 1) wf |= __shfl_down(wf, d, 64);
     if ((tid & 63) == 0 && wf) atomicOr(&Ak->scal->flags, wf);
     if constexpr (WEIGH) {
-        for (int d = 32; d >= 1; d >>= 1) {
-            unsigned long long o = shfl_down_u64(code, d);
-            code = o > code ? o : code;
-        }
-        if ((tid & 63) == 0) s_max[tid >> 6] = code;
-        __syncthreads();
+        // (s_max was written after phase A; the barrier after the infection-term rounds lies in between)
         if (tid == 0) {
             unsigned long long c = s_max[0];
             for (int w = 1; w < CTPB / 64; w++) c = s_max[w] > c ? s_max[w] : c;
@@ -1081,6 +1098,7 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
     // The cooperative kernel takes the square root of the observation variance without the power-of-two scaling that
     // arguments below 2^-767 need; the argument is a positive integer times p (1 - p), so a parameter set with a test
     // probability in (0, 2^-700) always runs the per-thread kernel.
+    if (WEIGH && (A.o_out || A.r_out || A.newinf_out || A.hist)) return hipErrorInvalidValue;   // the weighing builds have no per-particle outputs
     if (!WEIGH && A.n == 1 && g_coop == 1) {                    // a lone particle: one lane per age bin
         k_step_one<<<dim3(1), dim3(64), 0, c->stream>>>(A, c->d_params);
         return hipGetLastError();
@@ -3035,7 +3053,7 @@ static int launch_predict(epi_ctx* c, epi_belief* b, const UpdateScratch& sc, do
         c->timed.emplace_back(e0, e1);
     }
     HIPCHECK(hipEventRecord(e0, c->stream));
-    HIPCHECK(launch_step<true>(c, A));
+    HIPCHECK(launch_step<true>(c, A));                                  // (no per-particle outputs: the weighing build has none)
     HIPCHECK(hipEventRecord(e1, c->stream));
     if (!(c->timing && timed)) c->ev_valid = true;
     b->seed = seed; b->step = step;
