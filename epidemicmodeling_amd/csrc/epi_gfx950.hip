@@ -735,7 +735,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // ballot per draw: no atomics, no prefix sums); round 1 of phase C reads the segments as one list.  A draw that
     // finds its segment full is remembered (bit 2 i + j) and finished by its thread after the loop.
     unsigned int wcount = 0u;                                                      // entries of this wave's segment (wave-uniform)
+    constexpr bool SMALLH = HC > 0 && HC <= 16;                                    // the masks of leftover draws / terms fit 32 bits
     unsigned long long over0 = 0ULL, over1 = 0ULL;                                 // bins 0..31 / 32..63
+    unsigned int over_s = 0u;                                                      // SMALLH: all bins
     const int lane = tid & 63;
     unsigned short* const qseg = q0 + (unsigned int)(tid >> 6) * QSEG;
 #pragma unroll 1
@@ -779,6 +781,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                     if (st != BTRS_ACCEPT) {
                         // bit 15: attempt 0 is settled (rejected), the draw goes on with attempt 1
                         if (pos < QSEG) qseg[pos] = (unsigned short)(lp | (i << 8) | (j << 14) | ((st == BTRS_REJECT) << 15));
+                        else if (SMALLH) over_s |= 1u << (2 * i + j);
                         else if (i < 32) over0 |= 1ULL << (2 * i + j);
                         else over1 |= 1ULL << (2 * (i - 32) + j);
                     }
@@ -789,7 +792,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
     if (lane == 0) qw[tid >> 6] = wcount < QSEG ? wcount : QSEG;
-    for (int half = 0; half < 2; half++) {
+    if constexpr (SMALLH) over0 = over_s;
+    for (int half = 0; half < (SMALLH ? 1 : 2); half++) {
         unsigned long long om = half ? over1 : over0;
         while (om) {                                                               // segment full: finish here
             const int bit = __ffsll((long long)om) - 1;
@@ -898,11 +902,21 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // (the circular shift of simulate.jl:145).  A term is settled here when its normal comes from the inside of a
     // strip and the squeeze accepts it; the others are queued and repeat attempt 0 in full in round 1 of phase E.
     int32_t sum_inf = 0;
-    unsigned long long g_over = 0ULL;  // terms that found the queue full
+    typename std::conditional<SMALLH, unsigned int, unsigned long long>::type g_over = 0;  // terms that found the queue full
     uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
+    // The particle's source column and its generator are formed again from the thread index here (one more read of the
+    // ancestor index, from the cache): carried over from phase A they would sit in registers through the binomial rounds,
+    // which need every one of them, or go through the stack.
+    int lpd = lp;
+    asm volatile("" : "+v"(lpd));
+    const int64_t md = base + lpd;
+    const int64_t mcd = FULL ? (md < A.n ? md : A.n - 1) : md;
+    const int64_t srcd = active ? (A.anc ? (int64_t)A.anc[mcd] : mcd) : 0;
+    const Rng gd = rng_make(A.seed, A.slot0 + (uint64_t)md, A.step);
+    auto ld_d = [&](int64_t row) -> int32_t { return in[row * is + srcd]; };
     const int nterm = nown;
     const int i_first = nterm > 0 ? bin_of(0) : 0;
-    int32_t I_next = (active && nterm > 0) ? ld_in(2 + i_first) : 0;               // loads run one bin ahead
+    int32_t I_next = (active && nterm > 0) ? ld_d(2 + i_first) : 0;                // loads run one bin ahead
     int2 sp_next = slots[i_first * PW + lp];                                       // so does the read of the bin's slot
 #pragma unroll 1
     for (int k = 0; k < nterm; k++) {
@@ -918,7 +932,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (k + 1 < nterm) sp_next = slots[i_next * PW + lp];                  // bin of the next iteration (another slot than this bin's)
             const int32_t sympt = sp.x, pos = sp.y;
             int32_t Ii = I_next;
-            if (k + 1 < nterm) I_next = ld_in(2 + i_next);                         // bin of the next iteration
+            if (k + 1 < nterm) I_next = ld_d(2 + i_next);                          // bin of the next iteration
             double pr = div_unscaled((double)sympt, (double)Ii);                   // simulate.jl:104
             if (pr != pr) pr = 0.0;                                                // simulate.jl:105
             const double om = 1.0 - pr;
@@ -926,7 +940,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             for (int r = 0; r <= D; r++) {                                         // simulate.jl:110-126
                 int32_t tv;
                 if (r == D) tv = pos;
-                else tv = (i >= 1) ? ld_in(tests_row(H, r, i)) : 0;
+                else tv = (i >= 1) ? ld_d(tests_row(H, r, i)) : 0;
                 const int32_t ts = (int32_t)__builtin_floor(om * (double)tv);
                 if (r == 0) { R += ts; Ii -= ts; }
                 else if (i + 1 < H) st_out(tests_row(H, r - 1, i + 1), ts);
@@ -939,7 +953,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             uint32_t wz = z_odd, wu = w_odd;
             if ((it & 1) == 0) {                                                   // an even term generates the block of its pair
                 uint32_t w[4];
-                rng_block(g, K_GAMMA, (uint32_t)it >> 1, 0, w);
+                rng_block(gd, K_GAMMA, (uint32_t)it >> 1, 0, w);
                 wz = w[0]; z_odd = w[1]; wu = w[2]; w_odd = w[3];
             }
 #ifdef EPI_X_SKIP_G
@@ -964,14 +978,14 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             }
         }
         const bool gpushed = q_push(gfail, (unsigned short)(lp | (it << 8)), q0, &qn[spare], QCAP);
-        if (gfail && !gpushed) g_over |= 1ULL << it;                               // queue full: finished after the loop
+        if (gfail && !gpushed) g_over |= (decltype(g_over))1 << it;                // queue full: finished after the loop
     }
     while (g_over) {
         const int it = __ffsll((long long)g_over) - 1;
-        g_over &= g_over - 1ULL;
+        g_over &= g_over - 1;
         const int i = it == 0 ? H - 1 : it - 1;
         const int32_t Ii = slots[i * PW + lp].x;
-        gslots[i * PW + lp] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, g, (uint32_t)it, screen);
+        gslots[i * PW + lp] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, gd, (uint32_t)it, screen);
     }
 
     // the other chunks' shares of the particle's integer sums (order is immaterial), ahead of the barriers of phase E
@@ -1035,7 +1049,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         int lpf = lp;
         asm volatile("" : "+v"(lpf));
         auto st_end = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[lpf], v); };
-        S = ld_in(0); R_pre = ld_in(1);
+        S = ld_d(0); R_pre = ld_d(1);
         R += R_pre;
         if constexpr (NC > 1) {
             R += acc[lp];
@@ -1051,20 +1065,21 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         st_end(2, newi);                                                                        // simulate.jl:147
         st_end(0, S - newi);                                                                    // simulate.jl:148
         st_end(1, R);
-        const bool real = !FULL || m < Ak->n;                                                   // not a surplus thread of a padded launch
+        const bool real = !FULL || md < Ak->n;                                                   // not a surplus thread of a padded launch
         if (!real) flags = 0u;
         if constexpr (OUTS) {
-            if (Ak->o_out && real) Ak->o_out[m] = o_sum;
-            if (Ak->newinf_out && real) Ak->newinf_out[m] = newi;
+            if (Ak->o_out && real) Ak->o_out[md] = o_sum;
+            if (Ak->newinf_out && real) Ak->newinf_out[md] = newi;
             if (Ak->r_out && real) {
-                const int64_t prow = Ak->a_div > 1 ? m / Ak->a_div : m;
+                const int64_t prow = Ak->a_div > 1 ? md / Ak->a_div : md;
                 const double ap = Ak->a_prev_dev ? Ak->a_prev_dev[prow * Ak->a_row_stride + Ak->a_prev_col] : Ak->a_prev;
-                Ak->r_out[m] = reward_of(P, sum_inf + newi, a, ap);
+                const double af = Ak->a_dev ? Ak->a_dev[prow * Ak->a_row_stride + Ak->a_col] : Ak->a;   // read again rather than kept since phase A
+                Ak->r_out[md] = reward_of(P, sum_inf + newi, af, ap);
             }
             if (Ak->hist && real) {
                 int32_t* hist = Ak->hist;
                 const int64_t hn = Ak->n;
-                hist[m] = S; hist[hn + m] = suminf_pre; hist[2 * hn + m] = R_pre; hist[3 * hn + m] = o_sum;
+                hist[md] = S; hist[hn + md] = suminf_pre; hist[2 * hn + md] = R_pre; hist[3 * hn + md] = o_sum;
             }
         }
     }
