@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${ROUND:-r3}_final
 rm -rf $O gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c gpurun_out/pmc_fetch gpurun_out/pmc_write /tmp/prof_final
 mkdir -p $O/pmc
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -- python3 bench.py --steps 5 --warmup 1 --no-cpu > $O/prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final -- python3 bench.py --no-cpu > $O/prof.log 2>&1
 cp $(find /tmp/prof_final -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
 bash tools/pmc_step.sh > $O/pmc_step.log 2>&1
