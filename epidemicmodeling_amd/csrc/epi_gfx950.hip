@@ -560,14 +560,19 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 // in each phase of k_step_coop to g_phase[]; epi_debug_phase_times reads and clears them.
 #ifdef EPI_PHASE_STAMPS
 __device__ unsigned long long g_phase[16];
-#define EPI_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_phase[k], now_ - stamp_); stamp_ = now_; } } while (0)
+// (the counter is read by an instruction of its own with a memory clobber: the compiler may not move a phase's LDS and
+// global accesses across it, which it does with the plain builtin)
+__device__ __forceinline__ unsigned long long epi_ticks()
+{
+    unsigned long long t;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define EPI_STAMP(k) do { const unsigned long long now_ = epi_ticks(); if (threadIdx.x == 0) atomicAdd(&g_phase[k], now_ - stamp_); stamp_ = now_; } while (0)
 #else
 #define EPI_STAMP(k) do { } while (0)
 #endif
 
-#ifndef EPI_X_CUT
-#define EPI_X_CUT 0
-#endif
 #ifndef EPI_COOP_BINOM_ROUNDS
 #define EPI_COOP_BINOM_ROUNDS 3
 #endif
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     int32_t S = 0, R = 0, R_pre = 0, o_sum = 0, suminf_pre = 0;
     unsigned long long code = 0ULL;
 #ifdef EPI_PHASE_STAMPS
-    unsigned long long stamp_ = __builtin_readcyclecounter();
+    unsigned long long stamp_ = epi_ticks();
 #endif
 
     // ---- A: stage the bins, observation moments -----------------------------------
@@ -758,23 +763,12 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2), "s"(bc.ppf), "s"(bc.hqp), "s"(bc.c3u), "s"(bc.c3d));
                 int st = BTRS_ACCEPT;
                 if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
-#ifdef EPI_X_SKIP_BDRAW
-                else if (bc.kind == 7) {
-#else
                 else if (bc.kind == 2) {
-#endif
                     if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts_quick(n, bc.btrs()), bc.side(), wa, wb, x);
-#ifdef EPI_X_NO_INV
-                    else if (n > 0) x = 0;
-#else
                     else if (n > 0) x = binom_inversion(n, bc.lnq, bc.sr, wa);
-#endif
                 }
                 const int32_t res = st != BTRS_ACCEPT ? n : (bc.flip != 0 ? n - x : x);   // an unsettled draw keeps n for phase C
                 if (j) nn.y = res; else nn.x = res;
-#ifdef EPI_X_SKIP_C
-                st = BTRS_ACCEPT;
-#endif
                 const unsigned long long mask = __ballot(st != BTRS_ACCEPT);
                 if (mask) {                                                        // wave-uniform
                     const unsigned int pos = wcount + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
@@ -805,6 +799,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         }
     }
 
+    EPI_STAMP(1);
     // ---- C: binomial rounds ----------------------------------------------------------------
     // Round r runs, in full, attempt r - 1 of the queued draws whose attempt 0 was left open and attempt r of those whose
     // attempt 0 was rejected (bit 15 of the entry).
@@ -860,9 +855,6 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 const CoopRec rec = crec[j * H + i];
                 const BtrsBin B{rec.ppx, rec.pq, rec.a0x2, rec.lpq};
                 const bool flip = rec.flip != 0;                                   // a queued draw is a rejection draw
-#if EPI_X_CUT == 1
-                slot_words[(i * PW + t) * 2 + j] = flip ? n : 0; continue;
-#endif
                 const Rng gt = rng_make(A.seed, A.slot0 + (uint64_t)(base + t), A.step);
                 // attempt 0 takes its half of the bin's first block, attempt a >= 1 half (a - 1) & 1 of block (a - 1) / 2 of the draw's own stream
                 const bool first = att == 0u;
@@ -871,19 +863,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 uint32_t w[4];
                 rng_block(gt, kind, (uint32_t)i, first ? 0u : (att - 1u) >> 1, w);
                 const uint32_t wa = hi ? w[2] : w[0], wb = hi ? w[3] : w[1];
-#if EPI_X_CUT == 2
-                slot_words[(i * PW + t) * 2 + j] = (wa ^ wb) & 1; continue;
-#endif
                 const BtrsConsts C = btrs_consts(n, B);
                 int32_t k;
-#if EPI_X_CUT == 3
-                slot_words[(i * PW + t) * 2 + j] = (int32_t)(C.spq + C.cfr) + C.ci + C.m + ((wa ^ wb) & 1); continue;
-#endif
                 if (n < lf_n) k = btrs_attempt_tab(C, B.lpq, lf_t, screen, wa, wb);
                 else k = btrs_attempt_far(C, B.lpq, LfTable{lf_t, lf_n}, screen, wa, wb);
-#if EPI_X_CUT == 4
-                slot_words[(i * PW + t) * 2 + j] = k < 0 ? 0 : k; continue;
-#endif
                 const bool fail = k < 0;
                 // the first rounds hand rejected draws on; after them (and when the queue is full) a draw is finished by the thread that holds it
                 const bool pushed = round < COOP_BINOM_ROUNDS && q_push(fail, entry, qnext, &qn[nxt], qcap_next);
@@ -956,11 +939,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 rng_block(gd, K_GAMMA, (uint32_t)it >> 1, 0, w);
                 wz = w[0]; z_odd = w[1]; wu = w[2]; w_odd = w[3];
             }
-#ifdef EPI_X_SKIP_G
-            if (true) gslots[i * PW + lp] = shape;
-#else
             if (gamma_is_zero(shape)) gslots[i * PW + lp] = 0.0;
-#endif
             else {
                 const GammaConsts G = gamma_consts(shape, screen);
                 float xf;
@@ -969,11 +948,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 // (a shape below 1 needs the boost's extra uniform: left to the rounds, which are not this loop's straight code)
                 if (gamma_fast(G, xf, wu, v) && inside && !G.boost) gslots[i * PW + lp] = (G.d * v) * theta_it;
                 else {
-#ifdef EPI_X_SKIP_E
-                    gslots[i * PW + lp] = 0.0;
-#else
                     slots[i * PW + lp] = make_int2(Ii, 0); gfail = true;
-#endif
                 }
             }
         }
@@ -988,6 +963,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         gslots[i * PW + lp] = gamma_from0(P.k[it] * (double)Ii, P.theta[it], &Dp->zig, gd, (uint32_t)it, screen);
     }
 
+    EPI_STAMP(3);
     // the other chunks' shares of the particle's integer sums (order is immaterial), ahead of the barriers of phase E
     if constexpr (NC > 1) {
         if (active && !lead) {

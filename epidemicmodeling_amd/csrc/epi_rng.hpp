@@ -590,9 +590,6 @@ EPI_HD int32_t btrs_attempt(const BtrsConsts& C, double lpq, const LfTable& lf, 
     float lvf = 0.f;
     if (screen) lvf = btrs_lv_screen(C, v, r_us);
 #endif
-#ifdef EPI_X_NO_TABLE
-    return k;
-#endif
     const double ub = btrs_ub(C, k, lpq, lf);
 #ifdef EPI_HAVE_SCREEN
     if (screen) {
@@ -672,11 +669,7 @@ __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, const BtrsSide& S
     k = C.ci + kf;
     const bool inr = (uint32_t)k <= (uint32_t)C.n;
     const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.200005f;
-#ifdef EPI_X_NO_B_BOUNDS
-    const int bd = BTRS_OPEN;
-#else
     const int bd = btrs_bounds(C, S, k, btrs_lv_screen(C, v, r_us));
-#endif
     return !sure ? BTRS_OPEN : (!inr ? BTRS_REJECT : (squeeze ? BTRS_ACCEPT : bd));
 }
 #else
