@@ -1,5 +1,6 @@
-"""Rollout rate against the state width H for the two step kernels (cooperative up to H = 15 by default, one thread
-per particle beyond).  GPU box, repository root: python3 tools/wide_state.py"""
+"""Rollout rate against the state width H for the default choice of step kernel (cooperative with one thread per particle
+up to H = 17, two up to H = 28, the per-thread kernel beyond) and for the per-thread kernel at every width.  GPU box,
+repository root: python3 tools/wide_state.py"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
