@@ -764,7 +764,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 int st = BTRS_ACCEPT;
                 if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
                 else if (bc.kind == 2) {
-                    if (n > 0 && (uint32_t)n >= bc.nthr) st = btrs_quick(btrs_consts_quick(n, bc.btrs()), bc.side(), wa, wb, x);
+                    // (without the screens -- the testing build's cross-check -- nothing is settled without the table)
+                    if (n > 0 && (uint32_t)n >= bc.nthr) st = SCREEN ? btrs_quick(btrs_consts_quick(n, bc.btrs()), bc.side(), wa, wb, x) : BTRS_OPEN;
                     else if (n > 0) x = binom_inversion(n, bc.lnq, bc.sr, wa);
                 }
                 const int32_t res = st != BTRS_ACCEPT ? n : (bc.flip != 0 ? n - x : x);   // an unsettled draw keeps n for phase C
