@@ -88,3 +88,30 @@ def test_a_failing_node_filter_child_is_reported_inside_the_block():
         else:
             os.environ["EPI_BENCH_NODE_DEVICES"] = saved
     assert "error" in nf and "ms_per_step" not in nf
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_the_contract_fields():
+    """The default (one GPU) form at a small population: one JSON line with the fields the driver reads, the roofline of
+    the step kernel from the run's own HIP-event time, and the CPU baseline timed on this host by the oracle."""
+    p = subprocess.run([sys.executable, BENCH, "--particles", "300000", "--steps", "3", "--warmup", "1"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    res = _json_line(p.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in res, key
+    assert res["n_gpus"] == 1 and res["steps"] == 3 and res["warmup"] == 1 and res["higher_is_better"] is True
+    assert res["unit"] == "particle-steps/s" and res["vs_baseline"] is None and res["data"] == "synthetic"
+    assert "workload" in res["config"] and res["config"]["particles"] == 300000 and "model" not in res["config"]
+    assert abs(res["value"] - 300000 * 3 / (res["ms_per_step"] * 3e-3)) <= 1e-6 * res["value"]
+    r = res["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"].startswith("k_step_coop<true")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["alg_bytes_per_particle_step"] * 300000 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert r["traffic"] is None or "committed" in r["traffic_source"]
+    assert 0 < r["kernel_ms"] <= res["ms_per_step"]
+    c = res["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "particle-steps/s" and "updates" in c["sample"]
+    assert res["value"] > c["value"]
+    assert res["diagnostics"]["flags"] == 0
