@@ -56,9 +56,7 @@ def step_kernel_name(H: int, D: int) -> str:
         return "k_step_coop<true, false, 14, true, true, 1>"
     if H < 18:
         return f"k_step_coop<true, {delay}, 0, true, false, 1>"
-    if H <= 28:
-        return f"k_step_coop<true, {delay}, 0, true, false, 2>"
-    return f"k_step<true, 0, {delay}, true>"
+    return f"k_step_coop<true, {delay}, 0, true, false, {2 if H <= 28 else 4}>"
 
 
 def observations(pomdp, count):

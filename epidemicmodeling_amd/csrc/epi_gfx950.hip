@@ -946,9 +946,18 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 float xf;
                 double v;
                 const bool inside = zig_fast(wz, ztab[wz & 255u], xf);
-                // (a shape below 1 needs the boost's extra uniform: left to the rounds, which are not this loop's straight code)
-                if (gamma_fast(G, xf, wu, v) && inside && !G.boost) gslots[i * PW + lp] = (G.d * v) * theta_it;
-                else {
+                // (a shape below 1 needs the boost's extra uniform: left to the rounds, which are not this loop's straight code --
+                // except in the builds for wide states, whose old ages have shapes below 1 in every lane: there the boost of
+                // a term the squeeze has settled is taken here, in line, when a good part of the wave needs it)
+                const bool fastok = gamma_fast(G, xf, wu, v) && inside;
+                bool boost_here = false;
+                if constexpr (NC > 1) boost_here = __popcll(__ballot(fastok && G.boost)) >= 16;   // (1, 4, 16 lanes measure the same; 40 is slower)
+                if (fastok && !G.boost) gslots[i * PW + lp] = (G.d * v) * theta_it;
+                else if (NC > 1 && fastok && boost_here) {
+                    uint32_t wb[4];
+                    rng_block(gd, K_BOOST, (uint32_t)it, 0, wb);
+                    gslots[i * PW + lp] = ((G.d * v) * s_exp(s_log(u01(wb[0])) / G.shape)) * theta_it;   // gamma_finish's expression
+                } else {
                     slots[i * PW + lp] = make_int2(Ii, 0); gfail = true;
                 }
             }
@@ -1095,16 +1104,24 @@ static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
         k_step_one<<<dim3(1), dim3(64), 0, c->stream>>>(A, c->d_params);
         return hipGetLastError();
     }
-    // States of 18 to 28 ages run the cooperative kernel with every particle split over two threads, which brings the
-    // footprint per workgroup back to a narrow state's (ensembles of 4 10^6 trajectories: H = 18 2.14 vs 2.02, H = 21 1.88 vs
-    // 1.77, H = 28 1.44 vs 1.26e9 particle-steps/s).  Beyond that most bins are old ages whose draws are cheap and never
-    // rejected, the cooperative rounds have little to share, and the per-thread kernel is the faster one (four threads
-    // per particle, measured: H = 42 0.90 vs 0.92, H = 56 0.69 vs 0.76e9).
+    // States of 18 ages and more run the cooperative kernel with every particle split over two threads (up to H = 28) or four,
+    // which brings the footprint per workgroup back to a narrow state's (ensembles, 10^9 particle-steps/s, against the
+    // per-thread kernel: H = 21 1.85 vs 1.55, H = 28 1.59 vs 1.26, H = 42 1.10 vs 0.89, H = 56 0.95 vs 0.75, H = 64 0.76 vs 0.71).
+    // What made the difference for the widest states is where the boost of a small shape is taken: old ages have Gamma
+    // shapes below 1 in every lane, and as long as all of those terms went through the retry queue (as they do for narrow
+    // states, where they are rare) the gamma round drowned in them and four threads per particle lost to one.
     if (!c->tiny_p && g_coop == 1 && c->P.H >= 18 && c->P.H <= 28 && A.screen) {
         const size_t ldw = coop_lds_bytes(c->P.H, 2);
         const dim3 grid((unsigned)ceil_div(A.n, CTPB / 2));
         if (c->P.D > 0) k_step_coop<WEIGH, true, 0, true, false, 2><<<grid, dim3(CTPB), ldw, c->stream>>>(A, c->d_params);
         else k_step_coop<WEIGH, false, 0, true, false, 2><<<grid, dim3(CTPB), ldw, c->stream>>>(A, c->d_params);
+        return hipGetLastError();
+    }
+    if (!c->tiny_p && g_coop == 1 && c->P.H > 28 && A.screen) {
+        const size_t ldw = coop_lds_bytes(c->P.H, 4);
+        const dim3 grid((unsigned)ceil_div(A.n, CTPB / 4));
+        if (c->P.D > 0) k_step_coop<WEIGH, true, 0, true, false, 4><<<grid, dim3(CTPB), ldw, c->stream>>>(A, c->d_params);
+        else k_step_coop<WEIGH, false, 0, true, false, 4><<<grid, dim3(CTPB), ldw, c->stream>>>(A, c->d_params);
         return hipGetLastError();
     }
     const size_t lds = coop_lds_bytes(c->P.H);

@@ -26,8 +26,8 @@ int epi_debug_screen(int enable);
 int epi_debug_f32_forms(epi_ctx *ctx, int mode, float first, float last, uint64_t *mismatches);
 /* Two implementations of the Philox-driven step kernel give identical results: the cooperative one
  * hands rejected sampler attempts to idle threads of the workgroup, the other loops per thread.
- * cooperative = 1 (default) picks by state width (cooperative up to H = 28: one thread per particle up to H = 17, two
- * from there, which keeps the LDS footprint of a workgroup that of a narrow state), 2 forces the cooperative kernel
+ * cooperative = 1 (default) is the cooperative kernel with one thread per particle up to H = 17, two up to H = 28 and
+ * four beyond (which keeps the LDS footprint of a workgroup that of a narrow state), 2 forces the cooperative kernel
  * with one thread per particle, 0 the per-thread one.  Testing aid, process-wide. */
 int epi_debug_step_impl(int cooperative);
 /* The cooperative step kernel settles most binomial rejection draws in its first phase without the log-factorial

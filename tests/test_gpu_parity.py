@@ -809,7 +809,7 @@ def test_wide_state_retry_queue_overflow_bit_exact(testing_lib):
     _, mu, _ = orc.log_weights(st0, 0.3, 0)
     o = int(np.median(mu))
     try:
-        for impl in (2, 0):                  # one thread per particle: with the cooperative rounds, then without them (the default at this width)
+        for impl in (2, 0, 1):               # one thread per particle with the cooperative rounds, without them, then the default (four threads per particle)
             check(lib.epi_debug_step_impl(impl))
             st = st0
             b = _belief(pomdp, st)
@@ -825,8 +825,8 @@ def test_wide_state_retry_queue_overflow_bit_exact(testing_lib):
 
 @pytest.mark.parametrize("H,D,n", [(14, 1, 800), (18, 0, 257), (19, 3, 1100), (21, 0, 1500), (22, 0, 1500), (25, 1, 129), (27, 7, 640), (28, 0, 4001), (28, 2, 700), (29, 1, 1500), (43, 0, 900), (56, 0, 3000), (56, 3, 333), (64, 7, 450)])
 def test_wide_state_bit_exact(H, D, n):
-    """States of 18 to 28 infection ages have every particle stepped by two threads, each owning every other pair of
-    infection terms and the age bins that seed them; wider ones run one thread per particle.  Random parameter sets at
+    """States of 18 to 28 infection ages have every particle stepped by two threads, wider ones by four, each owning every
+    second (fourth) pair of infection terms and the age bins that seed them.  Random parameter sets at
     the edges of the sampler regimes, population sizes that leave the last workgroup partial: plain steps with
     per-particle outputs, filter updates (the observation moments are summed in bin order by one of the two threads),
     and rollouts with per-particle actions and the history rows, all against the oracle."""

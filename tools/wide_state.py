@@ -1,5 +1,5 @@
 """Rollout rate against the state width H for the default choice of step kernel (cooperative with one thread per particle
-up to H = 17, two up to H = 28, the per-thread kernel beyond) and for the per-thread kernel at every width.  GPU box,
+up to H = 17, two up to H = 28, four beyond) and for the per-thread kernel at every width.  GPU box,
 repository root: python3 tools/wide_state.py"""
 import sys, time
 sys.path.insert(0, ".")
@@ -8,7 +8,7 @@ import epidemicmodeling_amd as em
 from epidemicmodeling_amd import _lib
 # the choice of step kernel is a switch of the testing build (include/epi_testing.h): make it the library every context uses
 lib = _lib._lib = _lib.load_testing()
-for H in (14, 16, 21, 28, 56, 64):
+for H in (14, 16, 21, 28, 42, 56, 64):
     pomdp = em.make_pomdp(LOD=5, horizon=H)
     n, T = 4_000_000, 10
     for impl in (1, 0):
