@@ -472,12 +472,14 @@ __global__ __launch_bounds__(64) void k_step_one(const StepArgs A, const DevPara
 // addressed by (slot, step, bin, attempt), so the result is bit-identical to the
 // per-thread kernel.
 //   A  load the particle, stage (I_i, tested_i) per age bin in LDS, log weight
-//   B  attempt 0 of both binomials of every bin; rejected draws -> queue
-//   C  retry rounds until the queue is empty (attempt r in round r)
-//   D  isolation bookkeeping per bin, attempt 0 of the gamma term; rejected -> queue
-//   E  gamma retry rounds
-//   F  infection sum in bin order, new infections, outputs
-// LDS: one 8-byte slot per (bin, thread) + two 2048-entry queues + three rotating entry counts.
+//   B  attempt 0 of both binomials of every bin without the log-factorial table (squeeze and series bounds);
+//      draws it rejects or leaves open -> queue
+//   C  three retry rounds (the next attempt in full, with the table), then a draw is finished by the thread that holds it
+//   D  isolation bookkeeping per bin, attempt 0 of the gamma term (ziggurat strip and squeeze); the rest -> queue
+//   E  one gamma retry round, then finished in thread
+//   F  S and R, infection sum in bin order, new infections, outputs
+// LDS: one 8-byte slot per (bin, particle) + a 2048- and a 1024-entry queue + three rotating entry counts + the ziggurat
+// strips + the per-bin records of the retry rounds.
 // ---------------------------------------------------------------------------
 #ifndef EPI_CTPB
 #define EPI_CTPB 256
@@ -1093,9 +1095,10 @@ static size_t coop_lds_bytes(int H, int NC = 1)
 template <bool WEIGH>
 static hipError_t launch_step(epi_ctx* c, const StepArgs& A)
 {
-    // The cooperative kernel needs 8 H bytes of LDS per particle: up to H = 14 four workgroups share a CU, up to H = 21
-    // three, and it is the faster one (rollouts: H = 14 3.4 vs 2.5e9 particle-steps/s, H = 21 1.97 vs 1.67e9); wider
-    // states would leave it two workgroups or one (H = 28: 1.08 vs 1.33e9, H = 56: 0.26 vs 0.79e9).
+    // The cooperative kernel needs 8 H bytes of LDS per particle: with one thread per particle four workgroups share a CU
+    // up to H = 14 and three up to H = 21 (wider states would leave two workgroups or one: H = 28 1.08 vs 1.33e9
+    // particle-steps/s for the per-thread kernel, H = 56 0.26 vs 0.79e9), which is why wider states split a particle over
+    // several threads (below).
     // The cooperative kernel takes the square root of the observation variance without the power-of-two scaling that
     // arguments below 2^-767 need; the argument is a positive integer times p (1 - p), so a parameter set with a test
     // probability in (0, 2^-700) always runs the per-thread kernel.
