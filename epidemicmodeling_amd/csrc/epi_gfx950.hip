@@ -561,7 +561,7 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
 // -DEPI_PHASE_STAMPS (variant builds for measurements only): thread 0 of every workgroup adds the clock ticks it spent
 // in each phase of k_step_coop to g_phase[]; epi_debug_phase_times reads and clears them.
 #ifdef EPI_PHASE_STAMPS
-__device__ unsigned long long g_phase[16];
+// (g_phase[] itself is defined beside the samplers, which count into it as well)
 // (the counter is read by an instruction of its own with a memory clobber: the compiler may not move a phase's LDS and
 // global accesses across it, which it does with the plain builtin)
 __device__ __forceinline__ unsigned long long epi_ticks()
@@ -764,6 +764,12 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 // all of the record before the first branch: the loads go out together and are waited for once
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2), "s"(bc.ppf), "s"(bc.hqp), "s"(bc.c3u), "s"(bc.c3d));
                 int st = BTRS_ACCEPT;
+#ifdef EPI_PHASE_STAMPS
+                if (bc.kind == 2) {
+                    const unsigned long long mb = __ballot(n > 0 && (uint32_t)n >= bc.nthr), mi = __ballot(n > 0 && (uint32_t)n < bc.nthr);
+                    if (lane == 0) { atomicAdd(&g_phase[16], mb ? 1ULL : 0ULL); atomicAdd(&g_phase[17], mi ? 1ULL : 0ULL); atomicAdd(&g_phase[18], (mb && mi) ? 1ULL : 0ULL); atomicAdd(&g_phase[19], (unsigned long long)__popcll(mi)); atomicAdd(&g_phase[21], 1ULL); }
+                }
+#endif
                 if (bc.kind == 1) x = n > 0 ? n : 0;                               // p >= 1
                 else if (bc.kind == 2) {
                     // (without the screens -- the testing build's cross-check -- nothing is settled without the table)
@@ -3240,8 +3246,8 @@ int epi_pf_update_noalloc(epi_ctx* c, epi_belief* b, double a, int64_t o, uint64
 #ifdef EPI_PHASE_STAMPS
 int epi_debug_phase_times(unsigned long long* out)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    unsigned long long z[32] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif

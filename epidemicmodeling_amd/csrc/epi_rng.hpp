@@ -343,6 +343,9 @@ static
 const float EPI_RECIP[72] = { 0.0f, EPI_R(1), EPI_R(2), EPI_R(3), EPI_R(4), EPI_R(5), EPI_R(6), EPI_R(7),
     EPI_R8(8), EPI_R8(16), EPI_R8(24), EPI_R8(32), EPI_R8(40), EPI_R8(48), EPI_R8(56), EPI_R8(64) };
 constexpr int EPI_RECIP_N = 72;
+#ifdef EPI_PHASE_STAMPS
+__device__ unsigned long long g_phase[32];   // measurement builds: phase ticks and queue counters of the cooperative step kernel
+#endif
 
 // Sequential inversion from 0 in binary32 (n pp < 10: at most a few dozen terms matter):
 //   u = fl(w >> 8) 2^-24 + 2^-25 in (0, 1],  r_0 = exp(fl(n) lnq),  r_x = r_(x-1) (s ((fl(n) + 1 - x) (1 / x))),
@@ -366,6 +369,9 @@ EPI_HD int32_t binom_inversion(int32_t n, double lnq, double s, uint32_t wa)
 #pragma unroll 1
     for (int32_t xb = 1; __any(live); xb += 8) {
         float t8[8];
+#ifdef EPI_PHASE_STAMPS
+        { const unsigned long long ml = __ballot(live); if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_phase[20], 1ULL); atomicAdd(&g_phase[22], (unsigned long long)__popcll(ml)); } }
+#endif
         if (xb + 7 < EPI_RECIP_N) {
 #pragma unroll
             for (int k = 0; k < 8; k++) t8[k] = EPI_RECIP[xb + k];
@@ -669,6 +675,12 @@ __device__ __forceinline__ int btrs_quick(const BtrsConsts& C, const BtrsSide& S
     k = C.ci + kf;
     const bool inr = (uint32_t)k <= (uint32_t)C.n;
     const bool squeeze = us >= 0.07f && (0.92f - v) * C.b >= 4.200005f;
+#ifdef EPI_PHASE_STAMPS
+    {
+        const unsigned long long mm = __ballot(sure && inr && !squeeze), all = __ballot(true);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)all) - 1) { atomicAdd(&g_phase[6], (unsigned long long)__popcll(mm)); atomicAdd(&g_phase[7], (unsigned long long)__popcll(all)); }
+    }
+#endif
     const int bd = btrs_bounds(C, S, k, btrs_lv_screen(C, v, r_us));
     return !sure ? BTRS_OPEN : (!inr ? BTRS_REJECT : (squeeze ? BTRS_ACCEPT : bd));
 }
