@@ -265,6 +265,12 @@ __device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, 
     lo = __shfl_up(lo, d, 64); hi = __shfl_up(hi, d, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int from)
+{
+    unsigned int lo = (unsigned int)v, hi = (unsigned int)(v >> 32);
+    lo = __shfl(lo, from, 64); hi = __shfl(hi, from, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ double shfl_down_f64(double v, int d) { return u2d(shfl_down_u64(d2u(v), d)); }
 
 // ---------------------------------------------------------------------------
@@ -1201,12 +1207,13 @@ __global__ __launch_bounds__(TPB) void k_wsum(int64_t n, const double* __restric
     __shared__ double s_sq[TPB / 64];
     const double lwmax = LOCAL ? lwmax_decode(scal->lwmax_bits) : (lwmax_src ? *lwmax_src : scal->lwmax);
     const double scale = u2d((uint64_t)(F + 1023) << 52);
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // (the tile's weights in any order: consecutive lanes read consecutive log weights)
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x;
     unsigned long long sum = 0ULL;
     double sq = 0.0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
-        int64_t i = base + j;
+        int64_t i = base + (int64_t)j * TPB;
         if (i < n) {
             const double wd = __builtin_floor(s_exp(lw[i] - lwmax) * scale);     // quantize(), before its conversion
             sum += (unsigned long long)wd;
@@ -1234,46 +1241,54 @@ __global__ __launch_bounds__(1024) void k_wscan(int64_t nb, unsigned long long* 
                                                 const double* __restrict__ lwmax_src = nullptr, double* __restrict__ totals_out = nullptr)
 {
     __shared__ unsigned long long s_w[16];
-    __shared__ unsigned long long s_carry;
     __shared__ double s_q[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (t == 0) s_carry = 0ULL;
+    // Every wave takes a run of consecutive tiles.  First sweep: the run's total (independent loads, one reduction); the
+    // waves' totals are exchanged once; second sweep: the prefixes, 256 tiles at a time -- four per lane, scanned in the
+    // lane, then one scan of the lanes' totals -- with the running total in a register (no barrier inside the loop).
+    constexpr int PER_LANE = 4, PER_TRIP = 64 * PER_LANE;
+    const int64_t per = (((nb + 15) / 16) + PER_TRIP - 1) / PER_TRIP * PER_TRIP, first = (int64_t)wv * per, last = first + per < nb ? first + per : nb;
+    unsigned long long mine = 0ULL;
     double sq = 0.0;
+#pragma unroll 8
+    for (int64_t i = first + lane; i < last; i += 64) { mine += blocksum[i]; sq += blocksq[i]; }
+    for (int d = 32; d >= 1; d >>= 1) { mine += shfl_down_u64(mine, d); sq += shfl_down_f64(sq, d); }
+    if (lane == 0) { s_w[wv] = mine; s_q[wv] = sq; }
     __syncthreads();
-    for (int64_t base = 0; base < nb; base += 1024) {
-        int64_t i = base + t;
-        unsigned long long v = i < nb ? blocksum[i] : 0ULL;
-        if (i < nb) sq += blocksq[i];
-        unsigned long long incl = v;
+    unsigned long long carry = 0ULL, total = 0ULL;
+    for (int w = 0; w < 16; w++) { if (w < wv) carry += s_w[w]; total += s_w[w]; }
+    for (int64_t b = first; b < last; b += PER_TRIP) {
+        const int64_t i0 = b + (int64_t)lane * PER_LANE;
+        unsigned long long v[PER_LANE];
+        unsigned long long run = 0ULL;
+#pragma unroll
+        for (int k = 0; k < PER_LANE; k++) {
+            const unsigned long long x = i0 + k < last ? blocksum[i0 + k] : 0ULL;
+            v[k] = run;                                                            // exclusive within the lane
+            run += x;
+        }
+        unsigned long long incl = run;
         for (int d = 1; d < 64; d <<= 1) {
             unsigned long long o = shfl_up_u64(incl, d);
             if (lane >= d) incl += o;
         }
-        if (lane == 63) s_w[wv] = incl;
-        __syncthreads();
-        unsigned long long woff = 0ULL;
-        for (int w = 0; w < wv; w++) woff += s_w[w];
-        unsigned long long carry = s_carry;
-        if (i < nb) blocksum[i] = carry + woff + incl - v;
-        __syncthreads();
-        if (t == 1023) s_carry = carry + woff + incl;
-        __syncthreads();
+        const unsigned long long lane_before = carry + incl - run;
+#pragma unroll
+        for (int k = 0; k < PER_LANE; k++) if (i0 + k < last) blocksum[i0 + k] = lane_before + v[k];
+        carry += shfl_u64(incl, 63);
     }
-    for (int d = 32; d >= 1; d >>= 1) sq += shfl_down_f64(sq, d);
-    if (lane == 0) s_q[wv] = sq;
-    __syncthreads();
     if (t == 0) {
         double q = 0.0;
         for (int w = 0; w < 16; w++) q += s_q[w];
-        scal->w_local = s_carry;
+        scal->w_local = total;
         scal->sumsq = q;
-        if (local) { scal->lwmax = lwmax_decode(scal->lwmax_bits); scal->w_off = 0ULL; scal->w_total = s_carry; }
+        if (local) { scal->lwmax = lwmax_decode(scal->lwmax_bits); scal->w_off = 0ULL; scal->w_total = total; }
         scal->lwmax_bits = 0ULL;
         *big_count = 0ULL;
         if (totals_out) {
             const double g = *lwmax_src;
             scal->lwmax = g;
-            totals_out[0] = (double)s_carry; totals_out[1] = q; totals_out[2] = (double)scal->flags; totals_out[3] = g;
+            totals_out[0] = (double)total; totals_out[1] = q; totals_out[2] = (double)scal->flags; totals_out[3] = g;
             scal->flags = 0u;
         }
     }
@@ -1502,16 +1517,25 @@ __global__ __launch_bounds__(TPB) void k_wcum_scatter(int64_t n, const double* _
                                                        int32_t* __restrict__ anc, unsigned long long* __restrict__ big_count, BigRange* __restrict__ big)
 {
     __shared__ unsigned long long s_w[TPB / 64];
+    __shared__ unsigned long long s_tile[SCAN_TILE + SCAN_TILE / SCAN_ITEMS];  // a pad word per thread's run: its lanes read distinct banks
     const double lwmax = scal->lwmax;
     const double scale = u2d((uint64_t)(F + 1023) << 52);
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    const int64_t tile = (int64_t)blockIdx.x * SCAN_TILE;
+    const int64_t base = tile + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // the tile's log weights are read with consecutive lanes on consecutive particles and turned into weights; a thread
+    // then takes its run of consecutive weights from LDS
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        const int e = j * TPB + (int)threadIdx.x;
+        const int64_t i = tile + e;
+        s_tile[e + e / SCAN_ITEMS] = (i < n) ? quantize(lw[i], lwmax, scale) : 0ULL;
+    }
+    __syncthreads();
     unsigned long long v[SCAN_ITEMS];
     unsigned long long run = 0ULL;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
-        int64_t i = base + j;
-        unsigned long long w = (i < n) ? quantize(lw[i], lwmax, scale) : 0ULL;
-        run += w;
+        run += s_tile[(int)threadIdx.x * (SCAN_ITEMS + 1) + j];
         v[j] = run;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
