@@ -1,6 +1,7 @@
 #!/bin/bash
 # The round's final measurement set on one box (GPU box, repository root): kernel statistics of the bench command, the
-# default bench line, the SQ and TCC counter passes.  Results under gpurun_out/<round>_final (ROUND=r3 by default); copy what is kept to profiles/.
+# default bench line, the SQ and TCC counter passes.  (gpurun merges into the local gpurun_out/: delete the local pmc_* directories of
+# earlier calls before summarising with tools/pmc_valu.py / pmc_traffic.py, which read every file they find there.)  Results under gpurun_out/<round>_final (ROUND=r3 by default); copy what is kept to profiles/.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/${ROUND:-r3}_final
