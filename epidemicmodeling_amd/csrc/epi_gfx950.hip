@@ -581,6 +581,10 @@ __device__ __forceinline__ unsigned long long epi_ticks()
 #define EPI_STAMP(k) do { } while (0)
 #endif
 
+#ifndef EPI_D_AHEAD
+#define EPI_D_AHEAD 2
+#endif
+constexpr int D_AHEAD = EPI_D_AHEAD;
 #ifndef EPI_COOP_BINOM_ROUNDS
 #define EPI_COOP_BINOM_ROUNDS 3
 #endif
@@ -672,6 +676,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     // state rows: one coalesced 4-byte access per lane and row
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[lp], v); };
+    // Phase A's loads of the infection ages are requested here, all of them when their number is a constant of the build
+    // (else the first few, the rest running that far ahead of their use): a bin's arithmetic there is a few dozen
+    // instructions, a load from HBM takes the time of several hundred, a wave has at most three others to hide behind, and
+    // the set-up below and its barrier pass in the meantime.  (One bin ahead: 19.2 ms; four or eight: the same; all: 18.8.)
+    constexpr int A_AHEAD = HC > 0 ? HC : 4;
+    const bool a_every = NC == 1 || (WEIGH && lead);                               // this thread visits every bin in phase A
+    const int a_bins = a_every ? H : nown;
+    int32_t Iq[A_AHEAD];
+#pragma unroll
+    for (int k = 0; k < A_AHEAD; k++) Iq[k] = (active && k < a_bins) ? ld_in(2 + (a_every ? k : bin_of(k))) : 0;
     if (tid == 0) { qn[0] = 0u; qn[1] = 0u; qn[2] = 0u; }
     if (WEIGH && tid < CTPB / 64) s_max[tid] = 0ULL;
     if constexpr (NC > 1) for (int r = tid; r < 4 * PW; r += CTPB) acc[r] = 0;
@@ -700,12 +714,13 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         const bool moments = WEIGH && lead;
         const bool every = NC == 1 || moments;                                     // all bins, in order
         const int na = every ? H : nown;
-        int32_t I_next = na > 0 ? ld_in(2 + (every ? 0 : bin_of(0))) : 0;          // loads run one bin ahead of their use
 #pragma unroll 1
         for (int q = 0; q < na; q++) {
             const int i = every ? q : bin_of(q);
-            const int32_t Ii = I_next;
-            if (q + 1 < na) I_next = ld_in(2 + (every ? q + 1 : bin_of(q + 1)));
+            const int32_t Ii = Iq[0];
+#pragma unroll
+            for (int k = 0; k + 1 < A_AHEAD; k++) Iq[k] = Iq[k + 1];
+            if (q + A_AHEAD < na) Iq[A_AHEAD - 1] = ld_in(2 + (every ? q + A_AHEAD : bin_of(q + A_AHEAD)));
             int32_t already = 0;
             if (D > 0 && i >= 1)
                 for (int r = 0; r < D; r++) already += ld_in(tests_row(H, r, i));
@@ -851,16 +866,16 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if (tid == 0) qn[nxt == 2 ? 0 : nxt + 1] = 0u;
             const unsigned short* q = (round & 1u) ? q0 : q1;
             unsigned short* qnext = (round & 1u) ? q1 : q0;
+            auto at_of = [&](unsigned int e) -> unsigned int {
+                if (round != 1u) return e;
+                unsigned int seg = 0u, first = 0u;
+#pragma unroll
+                for (int w = 0; w + 1 < CTPB / 64; w++) if (e >= seg_end[w]) { seg = (unsigned int)w + 1u; first = seg_end[w]; }
+                return seg * QSEG + (e - first);
+            };
 #pragma unroll 1
             for (unsigned int e = tid; e < cnt; e += CTPB) {
-                unsigned int at = e;
-                if (round == 1u) {
-                    unsigned int seg = 0u, first = 0u;
-#pragma unroll
-                    for (int w = 0; w + 1 < CTPB / 64; w++) if (e >= seg_end[w]) { seg = (unsigned int)w + 1u; first = seg_end[w]; }
-                    at = seg * QSEG + (e - first);
-                }
-                const unsigned short entry = q[at];
+                const unsigned short entry = q[at_of(e)];
                 const int t = entry & 255, i = (entry >> 8) & 63, j = (entry >> 14) & 1;
 #ifdef EPI_PHASE_STAMPS
                 if (round == 1u && (entry >> 15)) atomicAdd(&g_phase[15], 1ULL);
@@ -914,7 +929,11 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     auto ld_d = [&](int64_t row) -> int32_t { return in[row * is + srcd]; };
     const int nterm = nown;
     const int i_first = nterm > 0 ? bin_of(0) : 0;
-    int32_t I_next = (active && nterm > 0) ? ld_d(2 + i_first) : 0;                // loads run one bin ahead
+    // the loads of the infection ages run D_AHEAD iterations ahead of their use
+    auto bin_of_iter = [&](int k) -> int { const int it = term_of(k); return it == 0 ? H - 1 : it - 1; };
+    int32_t Id[D_AHEAD];
+#pragma unroll
+    for (int k = 0; k < D_AHEAD; k++) Id[k] = (active && k < nterm) ? ld_d(2 + bin_of_iter(k)) : 0;
     int2 sp_next = slots[i_first * PW + lp];                                       // so does the read of the bin's slot
 #pragma unroll 1
     for (int k = 0; k < nterm; k++) {
@@ -929,8 +948,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             const int2 sp = sp_next;
             if (k + 1 < nterm) sp_next = slots[i_next * PW + lp];                  // bin of the next iteration (another slot than this bin's)
             const int32_t sympt = sp.x, pos = sp.y;
-            int32_t Ii = I_next;
-            if (k + 1 < nterm) I_next = ld_d(2 + i_next);                          // bin of the next iteration
+            int32_t Ii = Id[0];
+#pragma unroll
+            for (int r = 0; r + 1 < D_AHEAD; r++) Id[r] = Id[r + 1];
+            if (k + D_AHEAD < nterm) Id[D_AHEAD - 1] = ld_d(2 + bin_of_iter(k + D_AHEAD));
             double pr = div_unscaled((double)sympt, (double)Ii);                   // simulate.jl:104
             if (pr != pr) pr = 0.0;                                                // simulate.jl:105
             const double om = 1.0 - pr;
