@@ -543,6 +543,12 @@ __device__ __noinline__ double gamma_from0(double shape, double scale, const Zig
 struct alignas(8) CoopRec { double lpq; uint32_t ppx; float pq, a0x2; int32_t flip; };
 static_assert(sizeof(CoopRec) == 24, "three 8-byte words");
 
+// the number of lanes below this one whose bit is set in `mask` (two instructions, no lane mask to keep)
+__device__ __forceinline__ unsigned int rank_in(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+}
+
 // push `entry` for every lane that wants to (one LDS atomic per wave); false = queue full
 __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned short* q, unsigned int* qn, unsigned int cap)
 {
@@ -554,7 +560,7 @@ __device__ __forceinline__ bool q_push(bool want, unsigned short entry, unsigned
     if (lane == leader) base = atomicAdd(qn, (unsigned int)__popcll(mask));
     base = __shfl(base, leader, 64);
     if (!want) return true;
-    const unsigned int pos = base + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
+    const unsigned int pos = base + rank_in(mask);
     if (pos >= cap) return false;
     q[pos] = entry;
     return true;
@@ -782,6 +788,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 const uint32_t wa = j ? w[2] : w[0], wb = j ? w[3] : w[1];
                 int32_t x = 0;
                 const BinConsts bc = Dp->bc[j][i];                                 // wave-uniform: scalar loads
+                // (the generator's block is complete before the record is waited for: its instructions pass the loads' latency)
+                if (j == 0) asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
                 // all of the record before the first branch: the loads go out together and are waited for once
                 asm volatile("" :: "s"(bc.kind), "s"(bc.nthr), "s"(bc.flip), "s"(bc.ppx), "s"(bc.pq), "s"(bc.a0x2), "s"(bc.ppf), "s"(bc.hqp), "s"(bc.c3u), "s"(bc.c3d));
                 int st = BTRS_ACCEPT;
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
                 if (j) nn.y = res; else nn.x = res;
                 const unsigned long long mask = __ballot(st != BTRS_ACCEPT);
                 if (mask) {                                                        // wave-uniform
-                    const unsigned int pos = wcount + (unsigned int)__popcll(mask & ((1ULL << lane) - 1ULL));
+                    const unsigned int pos = wcount + rank_in(mask);
                     if (st != BTRS_ACCEPT) {
                         // bit 15: attempt 0 is settled (rejected), the draw goes on with attempt 1
                         if (pos < QSEG) qseg[pos] = (unsigned short)(lp | (i << 8) | (j << 14) | ((st == BTRS_REJECT) << 15));
