@@ -949,9 +949,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         const int i = it == 0 ? H - 1 : it - 1;
         const int i_next = NC == 1 ? it : term_of(k + 1) - 1;                      // bin of the next iteration (never bin H-1)
         bool gfail = false;
-        // the term's Gamma parameters (wave-uniform) are requested at the top of the iteration, not at their first use
+        // the term's Gamma parameters (wave-uniform)
         const double k_it = P.k[it], theta_it = P.theta[it];
-        asm volatile("" :: "s"(k_it), "s"(theta_it));
         if (active) {
             const int2 sp = sp_next;
             if (k + 1 < nterm) sp_next = slots[i_next * PW + lp];                  // bin of the next iteration (another slot than this bin's)
@@ -1085,8 +1084,17 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             if constexpr (OUTS) { o_sum += acc[PW + lp]; sum_inf += acc[2 * PW + lp]; suminf_pre += acc[3 * PW + lp]; }
         }
         double infsum = 0.0;
+        if constexpr (HC > 0) {
+            // (a constant number of terms: their reads go out together, the sum keeps its order)
+            double term[HC];
+#pragma unroll
+            for (int it = 0; it < HC; it++) term[it] = gslots[(it == 0 ? HC - 1 : it - 1) * PW + lp];
+#pragma unroll
+            for (int it = 0; it < HC; it++) infsum += term[it];                                  // simulate.jl:38-41
+        } else {
 #pragma unroll 1
-        for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * PW + lp];   // simulate.jl:38-41
+            for (int it = 0; it < H; it++) infsum += gslots[(it == 0 ? H - 1 : it - 1) * PW + lp];   // simulate.jl:38-41
+        }
         const int64_t denom = P.N - (int64_t)R;
         int32_t newi = 0;
         if (denom <= 0) flags |= EPI_F_BAD_DENOM;
@@ -1112,9 +1120,12 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             }
         }
     }
-    unsigned int wf = flags;
-    for (int d = 32; d >= 1; d >>= 1) wf |= __shfl_down(wf, d, 64);
-    if ((tid & 63) == 0 && wf) atomicOr(&Ak->scal->flags, wf);
+    // (flags are the exception: a wave without any skips the reduction and its six exchanges)
+    if (__any(flags != 0u)) {
+        unsigned int wf = flags;
+        for (int d = 32; d >= 1; d >>= 1) wf |= __shfl_down(wf, d, 64);
+        if ((tid & 63) == 0) atomicOr(&Ak->scal->flags, wf);
+    }
     if constexpr (WEIGH) {
         // (s_max was written after phase A; the barrier after the infection-term rounds lies in between)
         if (tid == 0) {
