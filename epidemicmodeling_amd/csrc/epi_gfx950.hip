@@ -683,10 +683,10 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     auto ld_in = [&](int64_t row) -> int32_t { return in[row * is + src]; };
     auto st_out = [&](int64_t row, int32_t v) { EPI_STREAM_STORE(&(out + (row * os + base))[lp], v); };
     // Phase A's loads of the infection ages are requested here, all of them when their number is a constant of the build
-    // (else the first few, the rest running that far ahead of their use): a bin's arithmetic there is a few dozen
+    // (else the first sixteen -- a thread's share of a wide state -- and the rest running that far ahead of their use): a bin's arithmetic there is a few dozen
     // instructions, a load from HBM takes the time of several hundred, a wave has at most three others to hide behind, and
     // the set-up below and its barrier pass in the meantime.  (One bin ahead: 19.2 ms; four or eight: the same; all: 18.8.)
-    constexpr int A_AHEAD = HC > 0 ? HC : 4;
+    constexpr int A_AHEAD = HC > 0 ? HC : 16;
     const bool a_every = NC == 1 || (WEIGH && lead);                               // this thread visits every bin in phase A
     const int a_bins = a_every ? H : nown;
     int32_t Iq[A_AHEAD];
