@@ -914,17 +914,8 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
             cur = nxt;
         }
     }
-    // the last round's readers of the first queue's entries are through before phase D pushes to it
-    __syncthreads();
-
-    EPI_STAMP(2);
-    // ---- D: isolation bookkeeping and the table-and-squeeze part of attempt 0 of the gamma terms ----------------
-    // iteration `it` handles bin (it == 0 ? H-1 : it-1), whose survivors seed infection term `it`
-    // (the circular shift of simulate.jl:145).  A term is settled here when its normal comes from the inside of a
-    // strip and the squeeze accepts it; the others are queued and repeat attempt 0 in full in round 1 of phase E.
-    int32_t sum_inf = 0;
-    typename std::conditional<SMALLH, unsigned int, unsigned long long>::type g_over = 0;  // terms that found the queue full
-    uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
+    // (phase D's first loads -- the ancestor index again, then the first infection ages -- are requested ahead of the barrier
+    // that ends the rounds: it passes while they arrive)
     // The particle's source column and its generator are formed again from the thread index here (one more read of the
     // ancestor index, from the cache): carried over from phase A they would sit in registers through the binomial rounds,
     // which need every one of them, or go through the stack.
@@ -942,6 +933,17 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     int32_t Id[D_AHEAD];
 #pragma unroll
     for (int k = 0; k < D_AHEAD; k++) Id[k] = (active && k < nterm) ? ld_d(2 + bin_of_iter(k)) : 0;
+    // the last round's readers of the first queue's entries are through before phase D pushes to it
+    __syncthreads();
+
+    EPI_STAMP(2);
+    // ---- D: isolation bookkeeping and the table-and-squeeze part of attempt 0 of the gamma terms ----------------
+    // iteration `it` handles bin (it == 0 ? H-1 : it-1), whose survivors seed infection term `it`
+    // (the circular shift of simulate.jl:145).  A term is settled here when its normal comes from the inside of a
+    // strip and the squeeze accepts it; the others are queued and repeat attempt 0 in full in round 1 of phase E.
+    int32_t sum_inf = 0;
+    typename std::conditional<SMALLH, unsigned int, unsigned long long>::type g_over = 0;  // terms that found the queue full
+    uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
     int2 sp_next = slots[i_first * PW + lp];                                       // so does the read of the bin's slot
 #pragma unroll 1
     for (int k = 0; k < nterm; k++) {
