@@ -720,9 +720,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
         const bool moments = WEIGH && lead;
         const bool every = NC == 1 || moments;                                     // all bins, in order
         const int na = every ? H : nown;
-        // (the default horizon's fourteen ages in two unrolled halves: the queue of requested ages then moves by renaming, not by
+        // (the default horizon's fourteen ages in two unrolled halves, a run-time horizon's four at a time: the queue of requested ages then moves by renaming, not by
         // thirteen copies per age -- 18.36 -> 18.09 ms; unrolled in full the loop spills: 19.0)
-        constexpr int A_UNROLL = HC == 14 ? 7 : 1;
+        constexpr int A_UNROLL = HC == 14 ? 7 : 4;
 #pragma unroll A_UNROLL
         for (int q = 0; q < na; q++) {
             const int i = every ? q : bin_of(q);
@@ -948,7 +948,9 @@ __global__ __launch_bounds__(CTPB, COOP_WAVES) void k_step_coop(const StepArgs A
     typename std::conditional<SMALLH, unsigned int, unsigned long long>::type g_over = 0;  // terms that found the queue full
     uint32_t z_odd = 0u, w_odd = 0u;   // words of the odd term of the pair block
     int2 sp_next = slots[i_first * PW + lp];                                       // so does the read of the bin's slot
-#pragma unroll 1
+    // (the default horizon's loop by pairs of terms: which term of a pair generates the pair's block is then known in the code)
+    constexpr int D_UNROLL = (HC == 14 && NC == 1) ? 2 : 1;
+#pragma unroll D_UNROLL
     for (int k = 0; k < nterm; k++) {
         const int it = term_of(k);
         const int i = it == 0 ? H - 1 : it - 1;
