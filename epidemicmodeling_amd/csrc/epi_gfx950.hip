@@ -477,11 +477,11 @@ __global__ __launch_bounds__(64) void k_step_one(const StepArgs A, const DevPara
 // round spreads the queued draws evenly over the 256 threads.  Variates are
 // addressed by (slot, step, bin, attempt), so the result is bit-identical to the
 // per-thread kernel.
-//   A  load the particle, stage (I_i, tested_i) per age bin in LDS, log weight
+//   A  the particle's infection ages (requested at the kernel's start) staged as (I_i, tested_i) per age bin in LDS, log weight
 //   B  attempt 0 of both binomials of every bin without the log-factorial table (squeeze and series bounds);
 //      draws it rejects or leaves open -> queue
 //   C  three retry rounds (the next attempt in full, with the table), then a draw is finished by the thread that holds it
-//   D  isolation bookkeeping per bin, attempt 0 of the gamma term (ziggurat strip and squeeze); the rest -> queue
+//   D  isolation bookkeeping per bin (loads two bins ahead), attempt 0 of the gamma term (ziggurat strip and squeeze); the rest -> queue
 //   E  one gamma retry round, then finished in thread
 //   F  S and R, infection sum in bin order, new infections, outputs
 // LDS: one 8-byte slot per (bin, particle) + a 2048- and a 1024-entry queue + three rotating entry counts + the ziggurat
